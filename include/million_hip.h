@@ -1,0 +1,167 @@
+/*
+ * million_hip.h — C ABI of libmillion_hip.so: MI355X-native (gfx950) PQ-KV attention hot path.
+ *
+ * This is the drop-in boundary below the reference's Python module `bindings`
+ * (reference: scripts/modeldb/bindings/bindings.template.cpp:11-63 declares, and
+ * scripts/modeldb/bindings/Interface.template.cu:16-147 defines, one torch-typed C++ symbol per
+ * (Ns, Lt, d, M, C) tuple).  Here ONE set of plain-C entry points sits behind all those names:
+ * plain pointers and sizes, no torch types.  The Python shim `bindings/` (built by `make bindings`)
+ * re-exports the reference's function names on top of these entry points.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name starts with `host_`;
+ *   - fp16 tensors are IEEE binary16 (`_Float16`), codes are uint8 (reference setup.py:10-11);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what the
+ *     reference launches on, Interface.template.cu:65,88,109);
+ *   - functions return MILLION_OK (0) or a negative error code and NEVER exit the process
+ *     (the reference's gpuErrchk calls exit(), Interface.template.cu:3-11); million_last_error()
+ *     returns a thread-local description of the last failure;
+ *   - no entry point allocates, frees or synchronises: all are legal inside hipGraph capture.
+ */
+#ifndef MILLION_HIP_H
+#define MILLION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MILLION_HIP_VERSION 1
+
+enum {
+    MILLION_OK = 0,
+    MILLION_ERR_SHAPE = -1,       /* unsupported or inconsistent shape */
+    MILLION_ERR_ALIGN = -2,       /* pointer / stride alignment */
+    MILLION_ERR_ARG = -3,         /* null pointer, bad enum, r out of range ... */
+    MILLION_ERR_WORKSPACE = -4,   /* workspace too small */
+    MILLION_ERR_LAUNCH = -5       /* hipGetLastError() after launch */
+};
+
+typedef void *million_stream_t;
+
+int million_version(void);
+const char *million_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Codebook preparation.
+ * Replaces: the per-call `.contiguous()` / transposes the reference applies to the centroid table
+ * (scripts/utils/pq_utils.py:149-159 set_cent; Interface.template.cu:49-50 key_cents.transpose).
+ * Input : cents (M, C, d_m) fp16 contiguous — the reference's codebook tensor (main_pq.py:252-260).
+ * Output: `prepared`, million_prepared_cents_bytes() bytes, two LDS-ready images back to back:
+ *           [0, M*C*d_m*2)            "row image"  [m][c][d_m]   (bank = code: used for K lookups)
+ *           [M*C*d_m*2, 2*M*C*d_m*2)  "col image"  [c][m][d_m]   (bank = subspace: used for V lookups)
+ * Call once per codebook (set_cent time); the decode entry points take prepared tables. */
+size_t million_prepared_cents_bytes(int M, int C, int d_m);
+int million_prepare_cents(const void *cents, int M, int C, int d_m, void *prepared,
+                          million_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PQ encode.
+ * Replaces: sa_encode_4d_keops (scripts/utils/pq_utils.py:451-499; call sites :189-190,:235-236,
+ * :292-293 and paged_pq_utils.py:161,167,241-242) plus the permute+cat that stores the codes
+ * (pq_utils.py:140-147, paged_pq_utils.py:162,173-175).
+ * codes[b,hk,t,m] = argmin_c sum_k (x[b,hk,t,m*d_m+k] - cents[m,c,k])^2, fp32 direct form,
+ * sequential k, lowest c wins ties; bit-exact with oracle/pq_oracle.c:pq_encode_direct. */
+enum {
+    MILLION_CODES_ROWMAJOR = 0,   /* dst (bs, nh_k, T_cap, M): reference layout, pq_utils.py:497-499 */
+    MILLION_CODES_KPAGES = 1,     /* dst pool (n_pool, page_size, M), via page ids                     */
+    MILLION_CODES_VPAGES = 2      /* dst pool (n_pool, M, page_size): transposed pages,                */
+                                  /*     paged_pq_utils.py:173-175, MILLION_技术分析文档.md:1330-1340   */
+};
+
+typedef struct {
+    uint32_t struct_size;         /* = sizeof(million_encode_desc) */
+    int32_t bs, nh_k, n;          /* X is (bs, nh_k, n, d) */
+    int32_t d, M, C;
+    int64_t x_stride_b, x_stride_h, x_stride_n;   /* in fp16 elements; innermost dim contiguous */
+    int32_t x_row_start, x_row_mod;   /* row t of X is read at ((x_row_start + t) % x_row_mod) if x_row_mod > 0
+                                         (residual ring buffer); else at t */
+    int32_t dst_layout;           /* MILLION_CODES_* */
+    int32_t dst_token_start;      /* first destination token index t0: tokens [t0, t0+n) are written */
+    int64_t dst_stride_b, dst_stride_h;   /* bytes; ROWMAJOR only (row stride is M bytes) */
+    int32_t page_size;            /* KPAGES / VPAGES */
+    int32_t n_pages_cap;          /* page_ids is (bs, nh_k, n_pages_cap) int32 */
+} million_encode_desc;
+
+int million_pq_encode(const million_encode_desc *desc, const void *x, const void *cents /* (M,C,d_m) fp16 */,
+                      void *dst, const int32_t *page_ids, million_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused decode-step attention.
+ * Replaces: flash_decoding_allocated_buffer<> (Interface.template.cu:26-120), i.e. the LUT matmul
+ * (:49-50), flash_decoding_split_kernel (Kernel.cuh:11-166), flash_decoding_residual_kernel
+ * (Kernel.cuh:1038-1209), torch::zeros (:104) and flash_decoding_reduce_kernel (Kernel.cuh:1211-1270)
+ * — one launch; and the intended 13-argument flash_decoding_paged_v (call site
+ * scripts/utils/paged_pq_utils.py:621-635; spec MILLION_技术分析文档.md:1292-1345) when the codes
+ * live in page pools.
+ *
+ * out[b,h,:] = softmax_j( q[b,h,:] . Kfull[b,hk,j,:] / sqrt(d) ) Vfull[b,hk,j,:],  hk = h / (nh/nh_k),
+ * Kfull = [ dequant(k codes, T tokens) ; k_resid valid rows (r rows) ], likewise V.
+ */
+enum {
+    MILLION_KV_ROWMAJOR = 0,      /* codes (bs, nh_k, T_cap, M) u8: reference layout (Interface.template.cu:29-30) */
+    MILLION_KV_PAGED = 1          /* K: pool (n_pool, page_size, M); V: pool (n_pool, M, page_size) — transposed  */
+                                  /* pages (paged_pq_utils.py:173-175); page ids (bs, nh_k, n_pages_cap).          */
+                                  /* The reference's 13-arg paged call mixes row-major K with paged V              */
+                                  /* (paged_pq_utils.py:621-635): k_layout and v_layout are independent.           */
+};
+
+typedef struct {
+    uint32_t struct_size;         /* = sizeof(million_attn_desc) */
+    int32_t bs, nh, nh_k;
+    int32_t d, M, C;
+    int32_t n_tokens;             /* T: quantised tokens per (b, hk); upper bound if dev_lengths != NULL */
+    int32_t r;                    /* valid residual rows, 0 <= r <= resid_cap */
+    int32_t resid_start;          /* first valid residual row (ring buffer); reference: always 0 */
+    int32_t resid_cap;            /* Lt: rows of the residual buffers (reference: Lt == d) */
+    int64_t resid_stride_b, resid_stride_h;   /* fp16 elements; row stride is d */
+    int32_t k_layout, v_layout;   /* MILLION_KV_* */
+    int32_t page_size;            /* PAGED: tokens per page (32, 64 or 128) */
+    int32_t n_pages_cap;          /* PAGED: row length of the page-id arrays */
+    int32_t page_ids_i64;         /* PAGED: 0 = page ids are int32, 1 = int64 (reference passes int64, paged_pq_utils.py:440) */
+    int32_t reserved0;
+    int64_t k_stride_b, k_stride_h;   /* ROWMAJOR: bytes between batches / kv heads of k_codes */
+    int64_t v_stride_b, v_stride_h;   /* ROWMAJOR: same for v_codes */
+    const int32_t *dev_lengths;   /* optional device array (bs, 4) = {n_tokens, r, resid_start, 0}: when set,
+                                     lengths are read on the device (graph replay with changing lengths) */
+} million_attn_desc;
+
+size_t million_attn_workspace_bytes(const million_attn_desc *desc);
+/* The workspace must be zeroed once after allocation (million_workspace_init or any memset); every call
+ * leaves it ready for the next one. */
+int million_workspace_init(void *workspace, size_t bytes, million_stream_t stream);
+
+int million_pq_decode_attn(const million_attn_desc *desc,
+                           const void *q,              /* (bs, nh, 1, d) fp16 contiguous */
+                           const void *k_codes,        /* ROWMAJOR tensor or K page pool */
+                           const void *v_codes,        /* ROWMAJOR tensor or V page pool */
+                           const void *k_page_ids,     /* k_layout PAGED only: int32 or int64, see page_ids_i64 */
+                           const void *v_page_ids,     /* v_layout PAGED only (may alias k_page_ids) */
+                           const void *k_cents_prepared, const void *v_cents_prepared,
+                           const void *k_resid, const void *v_resid,   /* (bs, nh_k, resid_cap, d) fp16 */
+                           void *out,                  /* (bs, nh, 1, d) fp16 */
+                           void *workspace, size_t workspace_bytes,
+                           million_stream_t stream);
+
+/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = MFMA fast path, 0 = generic. */
+int million_attn_kernel_kind(const million_attn_desc *desc);
+/* Force the generic kernel (A/B measurements and tests): 0 = auto (default), 1 = generic only. */
+void million_set_force_generic(int on);
+
+/* ------------------------------------------------------------------------------------------------
+ * Residual-window append.
+ * Replaces: the two slice-assign copies of DynamicPQCache.decoding (pq_utils.py:304-312) /
+ * PagedPQCache.decoding_with_pages (paged_pq_utils.py:377-380).
+ * Writes k_new/v_new (bs, nh_k, 1, d) into row (resid_start + r) % resid_cap of the residual buffers;
+ * when dev_lengths != NULL the row comes from the device array and r is incremented there. */
+int million_residual_append(const void *k_new, const void *v_new, void *k_resid, void *v_resid,
+                            int bs, int nh_k, int d, int resid_cap,
+                            int64_t resid_stride_b, int64_t resid_stride_h,
+                            int r, int resid_start, int32_t *dev_lengths, million_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MILLION_HIP_H */

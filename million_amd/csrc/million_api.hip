@@ -1,0 +1,237 @@
+// million_api.hip — C-ABI entry points of libmillion_hip.so (see include/million_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace million {
+
+static thread_local char g_err[512] = "";
+static int g_force_generic = 0;
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// ---- prepare_cents: (M, C, dm) -> row image [m][c][dm] followed by col image [c][m][dm] ----
+__global__ void prepare_cents_kernel(const f16 *__restrict__ src, f16 *__restrict__ dst, int M, int C, int dm) {
+    const int n = M * C * dm;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const f16 v = src[i];
+        const int k = i % dm, c = (i / dm) % C, m = i / (dm * C);
+        dst[i] = v;
+        dst[n + ((long long)c * M + m) * dm + k] = v;
+    }
+}
+
+// ---- residual append: one workgroup; lane-contiguous 2-byte copies of 2*bs*nh_k rows of d halfs ----
+__global__ void residual_append_kernel(const f16 *__restrict__ k_new, const f16 *__restrict__ v_new,
+                                       f16 *__restrict__ k_res, f16 *__restrict__ v_res,
+                                       int bs, int nh_k, int d, int cap, long long sb, long long sh,
+                                       int r, int rstart, int *dev_lengths) {
+    const int n = bs * nh_k * d;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int k = i % d, hk = (i / d) % nh_k, b = i / (d * nh_k);
+        int rr = r, rs = rstart;
+        if (dev_lengths) { rr = dev_lengths[b * 4 + 1]; rs = dev_lengths[b * 4 + 2]; }
+        const int row = (rs + rr) % cap;
+        const long long o = b * sb + hk * sh + (long long)row * d + k;
+        k_res[o] = k_new[i];
+        v_res[o] = v_new[i];
+    }
+    if (dev_lengths) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < bs; b += blockDim.x) dev_lengths[b * 4 + 1] += 1;
+    }
+}
+
+static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
+    if (!desc || desc->struct_size != sizeof(million_attn_desc)) { set_error("attn: bad desc / struct_size"); return MILLION_ERR_ARG; }
+    memset(&p, 0, sizeof(p));
+    p.bs = desc->bs; p.nh = desc->nh; p.nh_k = desc->nh_k; p.d = desc->d; p.M = desc->M; p.C = desc->C;
+    if (p.bs <= 0 || p.nh <= 0 || p.nh_k <= 0 || p.nh % p.nh_k) { set_error("attn: bs=%d nh=%d nh_k=%d", p.bs, p.nh, p.nh_k); return MILLION_ERR_SHAPE; }
+    p.G = p.nh / p.nh_k;
+    if (p.G > kMaxG) { set_error("attn: nh/nh_k=%d > %d", p.G, kMaxG); return MILLION_ERR_SHAPE; }
+    if (p.M <= 0 || p.d <= 0 || p.d % p.M || p.M % 4) { set_error("attn: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
+    p.dm = p.d / p.M;
+    if (p.C < 2 || p.C > 256) { set_error("attn: C=%d (uint8 codes)", p.C); return MILLION_ERR_SHAPE; }
+    p.T = desc->n_tokens; p.r = desc->r; p.rstart = desc->resid_start; p.rcap = desc->resid_cap;
+    if (p.T < 0 || p.rcap <= 0 || p.r < 0 || p.r > p.rcap || p.rstart < 0 || p.rstart >= p.rcap) {
+        set_error("attn: T=%d r=%d resid_start=%d resid_cap=%d", p.T, p.r, p.rstart, p.rcap);
+        return MILLION_ERR_ARG;
+    }
+    p.res_sb = desc->resid_stride_b; p.res_sh = desc->resid_stride_h;
+    p.k_sb = desc->k_stride_b; p.k_sh = desc->k_stride_h; p.v_sb = desc->v_stride_b; p.v_sh = desc->v_stride_h;
+    p.k_paged = desc->k_layout == MILLION_KV_PAGED;
+    p.v_paged = desc->v_layout == MILLION_KV_PAGED;
+    if ((desc->k_layout != MILLION_KV_PAGED && desc->k_layout != MILLION_KV_ROWMAJOR) ||
+        (desc->v_layout != MILLION_KV_PAGED && desc->v_layout != MILLION_KV_ROWMAJOR)) { set_error("attn: k_layout=%d v_layout=%d", desc->k_layout, desc->v_layout); return MILLION_ERR_ARG; }
+    p.page_size = desc->page_size; p.n_pages_cap = desc->n_pages_cap; p.ids64 = desc->page_ids_i64;
+    if (p.k_paged || p.v_paged) {
+        if (p.page_size != 32 && p.page_size != 64 && p.page_size != 128) { set_error("attn: page_size=%d (32, 64, 128)", p.page_size); return MILLION_ERR_SHAPE; }
+        if ((long long)p.n_pages_cap * p.page_size < p.T) { set_error("attn: n_pages_cap*page_size < n_tokens"); return MILLION_ERR_ARG; }
+    }
+    p.dev_lengths = desc->dev_lengths;
+    p.scale_log2e = 1.4426950408889634f / sqrtf((float)p.d);
+    p.slot_floats = (p.G * p.d + 2 * p.G + 3) / 4 * 4;
+    return MILLION_OK;
+}
+
+// Split policy: about one workgroup per CU over all (b, hk); a split is a multiple of 64 tokens and at
+// least 256 tokens long (the reference picks Ns from the binding name, pq_utils.py:8-22; here the
+// split count is internal and the Ns of the name is ignored).
+static void choose_splits(AttnParams &p, int min_tokens) {
+    const int bh = p.bs * p.nh_k;
+    int ns = (num_cus() + bh - 1) / bh;
+    if (ns > kMaxSplits) ns = kMaxSplits;
+    int by_len = (p.T + min_tokens - 1) / min_tokens;
+    if (by_len < 1) by_len = 1;
+    if (ns > by_len) ns = by_len;
+    if (ns < 1) ns = 1;
+    int len = (p.T + ns - 1) / ns;
+    len = (len + 63) / 64 * 64;
+    if (len < 64) len = 64;
+    ns = p.T > 0 ? (p.T + len - 1) / len : 1;
+    p.nsplit = ns;
+    p.split_len = len;
+}
+
+}  // namespace million
+
+using namespace million;
+
+extern "C" {
+
+int million_version(void) { return MILLION_HIP_VERSION; }
+const char *million_last_error(void) { return g_err; }
+void million_set_force_generic(int on) { g_force_generic = on; }
+
+size_t million_prepared_cents_bytes(int M, int C, int d_m) { return (size_t)2 * M * C * d_m * sizeof(f16); }
+
+int million_prepare_cents(const void *cents, int M, int C, int d_m, void *prepared, million_stream_t stream) {
+    if (!cents || !prepared) { set_error("prepare_cents: null pointer"); return MILLION_ERR_ARG; }
+    if (M <= 0 || C <= 0 || C > 256 || d_m <= 0) { set_error("prepare_cents: M=%d C=%d d_m=%d", M, C, d_m); return MILLION_ERR_SHAPE; }
+    const int n = M * C * d_m;
+    hipLaunchKernelGGL(prepare_cents_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const f16 *)cents, (f16 *)prepared, M, C, d_m);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("prepare_cents launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
+int million_pq_encode(const million_encode_desc *desc, const void *x, const void *cents, void *dst,
+                      const int32_t *page_ids, million_stream_t stream) {
+    if (!desc || desc->struct_size != sizeof(million_encode_desc)) { set_error("encode: bad desc / struct_size"); return MILLION_ERR_ARG; }
+    if (!x || !cents || !dst) { set_error("encode: null pointer"); return MILLION_ERR_ARG; }
+    EncParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const f16 *)x; p.cents = (const f16 *)cents; p.dst = (uint8_t *)dst; p.page_ids = page_ids;
+    p.bs = desc->bs; p.nh_k = desc->nh_k; p.n = desc->n; p.d = desc->d; p.M = desc->M; p.C = desc->C;
+    if (p.bs <= 0 || p.nh_k <= 0 || p.n < 0) { set_error("encode: bs=%d nh_k=%d n=%d", p.bs, p.nh_k, p.n); return MILLION_ERR_SHAPE; }
+    if (p.M <= 0 || p.d <= 0 || p.d % p.M) { set_error("encode: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
+    if (p.C < 1 || p.C > 256) { set_error("encode: C=%d (uint8 codes)", p.C); return MILLION_ERR_SHAPE; }
+    p.dm = p.d / p.M;
+    p.xsb = desc->x_stride_b; p.xsh = desc->x_stride_h; p.xsn = desc->x_stride_n;
+    p.xrow_start = desc->x_row_start; p.xrow_mod = desc->x_row_mod;
+    p.layout = desc->dst_layout; p.tok0 = desc->dst_token_start;
+    p.dsb = desc->dst_stride_b; p.dsh = desc->dst_stride_h;
+    p.page_size = desc->page_size; p.n_pages_cap = desc->n_pages_cap;
+    if (p.layout != MILLION_CODES_ROWMAJOR) {
+        if (p.layout != MILLION_CODES_KPAGES && p.layout != MILLION_CODES_VPAGES) { set_error("encode: dst_layout=%d", p.layout); return MILLION_ERR_ARG; }
+        if (!page_ids || p.page_size <= 0) { set_error("encode: paged destination needs page_ids and page_size"); return MILLION_ERR_ARG; }
+        if ((long long)p.n_pages_cap * p.page_size < (long long)p.tok0 + p.n) { set_error("encode: page table too short"); return MILLION_ERR_ARG; }
+    }
+    if (p.tok0 < 0) { set_error("encode: dst_token_start=%d", p.tok0); return MILLION_ERR_ARG; }
+    return launch_encode(p, (hipStream_t)stream);
+}
+
+size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
+    if (!desc || desc->nh_k <= 0 || desc->nh % desc->nh_k) return 0;
+    const int G = desc->nh / desc->nh_k;
+    const size_t slot = (size_t)(G * desc->d + 2 * G + 3) / 4 * 4;
+    size_t cnt = (size_t)desc->bs * desc->nh_k * sizeof(int);
+    cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
+    return cnt + (size_t)desc->bs * desc->nh_k * (kMaxSplits + 1) * slot * sizeof(float);
+}
+
+int million_workspace_init(void *workspace, size_t bytes, million_stream_t stream) {
+    if (!workspace) { set_error("workspace_init: null"); return MILLION_ERR_ARG; }
+    const hipError_t e = hipMemsetAsync(workspace, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("workspace_init: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
+int million_attn_kernel_kind(const million_attn_desc *desc) {
+    AttnParams p;
+    if (fill_attn_params(desc, p) != MILLION_OK) return -1;
+    return (!g_force_generic && attn_mfma_supported(p)) ? 1 : 0;
+}
+
+int million_pq_decode_attn(const million_attn_desc *desc, const void *q, const void *k_codes, const void *v_codes,
+                           const void *k_page_ids, const void *v_page_ids, const void *k_cents_prepared, const void *v_cents_prepared,
+                           const void *k_resid, const void *v_resid, void *out, void *workspace,
+                           size_t workspace_bytes, million_stream_t stream) {
+    AttnParams p;
+    const int rc = fill_attn_params(desc, p);
+    if (rc != MILLION_OK) return rc;
+    if (!q || !k_cents_prepared || !v_cents_prepared || !k_resid || !v_resid || !out || !workspace) { set_error("attn: null pointer"); return MILLION_ERR_ARG; }
+    if (p.T > 0 && (!k_codes || !v_codes)) { set_error("attn: null code pointer with n_tokens=%d", p.T); return MILLION_ERR_ARG; }
+    if (p.T > 0 && ((p.k_paged && !k_page_ids) || (p.v_paged && !v_page_ids))) { set_error("attn: paged layout without page ids"); return MILLION_ERR_ARG; }
+    if (workspace_bytes < million_attn_workspace_bytes(desc)) { set_error("attn: workspace %zu < %zu bytes", workspace_bytes, million_attn_workspace_bytes(desc)); return MILLION_ERR_WORKSPACE; }
+    if (((uintptr_t)q | (uintptr_t)k_codes | (uintptr_t)v_codes | (uintptr_t)k_resid | (uintptr_t)v_resid |
+         (uintptr_t)out | (uintptr_t)workspace | (uintptr_t)k_cents_prepared | (uintptr_t)v_cents_prepared) & 15) {
+        set_error("attn: every pointer must be 16-byte aligned");
+        return MILLION_ERR_ALIGN;
+    }
+    if ((!p.k_paged && ((p.k_sb | p.k_sh) & 15)) || (!p.v_paged && ((p.v_sb | p.v_sh) & 15))) { set_error("attn: code strides must be multiples of 16 bytes"); return MILLION_ERR_ALIGN; }
+    if ((p.res_sb | p.res_sh) & 7) { set_error("attn: residual strides must be multiples of 8 elements"); return MILLION_ERR_ALIGN; }
+    const size_t tab = (size_t)p.M * p.C * p.dm;
+    p.q = (const f16 *)q; p.k_codes = (const uint8_t *)k_codes; p.v_codes = (const uint8_t *)v_codes;
+    p.k_page_ids = k_page_ids; p.v_page_ids = v_page_ids;
+    p.k_tab = (const f16 *)k_cents_prepared; p.k_tab_col = p.k_tab + tab;
+    p.v_tab = (const f16 *)v_cents_prepared; p.v_tab_col = p.v_tab + tab;
+    p.k_res = (const f16 *)k_resid; p.v_res = (const f16 *)v_resid; p.out = (f16 *)out;
+    size_t cnt = (size_t)p.bs * p.nh_k * sizeof(int);
+    cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
+    p.ws_cnt = (int *)workspace;
+    p.ws_part = (float *)((char *)workspace + cnt);
+    if (!g_force_generic && attn_mfma_supported(p)) return launch_attn_mfma(p, (hipStream_t)stream);
+    choose_splits(p, 256);
+    p.nslots = p.nsplit + 1;
+    return launch_attn_generic(p, (hipStream_t)stream);
+}
+
+int million_residual_append(const void *k_new, const void *v_new, void *k_resid, void *v_resid, int bs, int nh_k,
+                            int d, int resid_cap, int64_t resid_stride_b, int64_t resid_stride_h, int r,
+                            int resid_start, int32_t *dev_lengths, million_stream_t stream) {
+    if (!k_new || !v_new || !k_resid || !v_resid) { set_error("residual_append: null pointer"); return MILLION_ERR_ARG; }
+    if (bs <= 0 || nh_k <= 0 || d <= 0 || resid_cap <= 0) { set_error("residual_append: bad shape"); return MILLION_ERR_SHAPE; }
+    if (!dev_lengths && (r < 0 || r >= resid_cap || resid_start < 0 || resid_start >= resid_cap)) {
+        set_error("residual_append: r=%d start=%d cap=%d (window full?)", r, resid_start, resid_cap);
+        return MILLION_ERR_ARG;
+    }
+    hipLaunchKernelGGL(residual_append_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const f16 *)k_new,
+                       (const f16 *)v_new, (f16 *)k_resid, (f16 *)v_resid, bs, nh_k, d, resid_cap,
+                       (long long)resid_stride_b, (long long)resid_stride_h, r, resid_start, dev_lengths);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("residual_append launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+"""Torch-facing wrappers over the C ABI (include/million_hip.h).  PyTorch is plumbing here: device
+memory, the current HIP stream and nothing else — all arithmetic runs in libmillion_hip.so.
+
+There is deliberately no CPU/eager fallback: a CPU tensor, a missing library or an unsupported shape
+raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_ws_cache = {}
+_prep_cache = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("million_amd ops need device tensors (no CPU fallback)")
+
+
+def prepare_cents(cents: torch.Tensor, cache: bool = True) -> torch.Tensor:
+    """(M, C, d_m) fp16 codebook -> LDS-ready images (row image + column image), see million_prepare_cents.
+
+    Cached per (storage, version): the reference passes the same codebook tensor on every call
+    (pq_utils.py:149-159, one table for all layers and heads)."""
+    _need_cuda(cents)
+    if cents.dtype != torch.float16 or cents.dim() != 3:
+        raise RuntimeError(f"codebook must be fp16 (M, C, d_m), got {cents.dtype} {tuple(cents.shape)}")
+    key = (cents.data_ptr(), cents._version, tuple(cents.shape), cents.device.index)
+    if cache and key in _prep_cache:
+        return _prep_cache[key]
+    lib = L.load()
+    c = cents.contiguous()
+    M, C, dm = c.shape
+    out = torch.empty(lib.million_prepared_cents_bytes(M, C, dm) // 2, dtype=torch.float16, device=c.device)
+    L.check(lib.million_prepare_cents(c.data_ptr(), M, C, dm, out.data_ptr(), _stream()), "million_prepare_cents")
+    if cache:
+        if len(_prep_cache) > 64:
+            _prep_cache.clear()
+        _prep_cache[key] = out
+    return out
+
+
+def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, layout: int = L.MILLION_CODES_ROWMAJOR,
+                   token_start: int = 0, n: Optional[int] = None, page_ids: Optional[torch.Tensor] = None,
+                   page_size: int = 0, x_row_start: int = 0, x_row_mod: int = 0) -> None:
+    """Encode rows of X (bs, nh_k, n_rows, d) fp16 and write the codes into `dst` in their final layout."""
+    _need_cuda(X, cents, dst, page_ids)
+    if X.dtype != torch.float16 or cents.dtype != torch.float16 or dst.dtype != torch.uint8:
+        raise RuntimeError("pq_encode: X and cents must be fp16, dst uint8")
+    if X.dim() != 4 or X.stride(3) != 1:
+        raise RuntimeError("pq_encode: X must be (bs, nh_k, n, d) with a contiguous last dim")
+    cents = cents.contiguous()
+    bs, nhk, n_rows, d = X.shape
+    M, C, dm = cents.shape
+    n = n_rows if n is None else n
+    desc = L.EncodeDesc()
+    desc.struct_size = ctypes.sizeof(L.EncodeDesc)
+    desc.bs, desc.nh_k, desc.n, desc.d, desc.M, desc.C = bs, nhk, n, d, M, C
+    desc.x_stride_b, desc.x_stride_h, desc.x_stride_n = X.stride(0), X.stride(1), X.stride(2)
+    desc.x_row_start, desc.x_row_mod = x_row_start, x_row_mod
+    desc.dst_layout, desc.dst_token_start = layout, token_start
+    if layout == L.MILLION_CODES_ROWMAJOR:
+        if dst.dim() != 4 or dst.stride(3) != 1 or dst.stride(2) != M or dst.shape[3] != M:
+            raise RuntimeError("pq_encode: row-major dst must be (bs, nh_k, T_cap, M) with dense rows")
+        if dst.shape[2] < token_start + n:
+            raise RuntimeError("pq_encode: dst too short")
+        desc.dst_stride_b, desc.dst_stride_h = dst.stride(0), dst.stride(1)
+    else:
+        if page_ids is None or page_ids.dtype != torch.int32 or not page_ids.is_contiguous():
+            raise RuntimeError("pq_encode: paged dst needs contiguous int32 page_ids (bs, nh_k, n_pages_cap)")
+        if not dst.is_contiguous():
+            raise RuntimeError("pq_encode: page pool must be contiguous")
+        desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
+    lib = L.load()
+    L.check(lib.million_pq_encode(ctypes.byref(desc), X.data_ptr(), cents.data_ptr(), dst.data_ptr(),
+                                  _ptr(page_ids), _stream()), "million_pq_encode")
+
+
+def pq_encode(X: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
+    """Drop-in for sa_encode_4d_keops (reference pq_utils.py:451-499): (bs, nh_k, n, d) -> (bs, nh_k, n, M) u8."""
+    bs, nhk, n, d = X.shape
+    codes = torch.empty(bs, nhk, n, cents.shape[0], dtype=torch.uint8, device=X.device)
+    if n:
+        pq_encode_into(X, cents, codes)
+    return codes
+
+
+def attn_workspace(desc: L.AttnDesc, device: torch.device) -> torch.Tensor:
+    lib = L.load()
+    need = lib.million_attn_workspace_bytes(ctypes.byref(desc))
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)   # zeroed once; every call leaves it ready
+        _ws_cache[key] = ws
+    return ws
+
+
+def make_attn_desc(q, k_res, *, nh_k, M, C, n_tokens, r, resid_start=0, k_paged=False, v_paged=False,
+                   page_size=0, n_pages_cap=0, page_ids_i64=False, k_codes=None, v_codes=None,
+                   dev_lengths=None) -> L.AttnDesc:
+    bs, nh, _, d = q.shape
+    desc = L.AttnDesc()
+    desc.struct_size = ctypes.sizeof(L.AttnDesc)
+    desc.bs, desc.nh, desc.nh_k, desc.d, desc.M, desc.C = bs, nh, nh_k, d, M, C
+    desc.n_tokens, desc.r, desc.resid_start, desc.resid_cap = n_tokens, r, resid_start, k_res.shape[2]
+    desc.resid_stride_b, desc.resid_stride_h = k_res.stride(0), k_res.stride(1)
+    desc.k_layout = L.MILLION_KV_PAGED if k_paged else L.MILLION_KV_ROWMAJOR
+    desc.v_layout = L.MILLION_KV_PAGED if v_paged else L.MILLION_KV_ROWMAJOR
+    desc.page_size, desc.n_pages_cap, desc.page_ids_i64 = page_size, n_pages_cap, int(page_ids_i64)
+    if not k_paged and k_codes is not None:
+        desc.k_stride_b, desc.k_stride_h = k_codes.stride(0), k_codes.stride(1)
+    if not v_paged and v_codes is not None:
+        desc.v_stride_b, desc.v_stride_h = v_codes.stride(0), v_codes.stride(1)
+    desc.dev_lengths = _ptr(dev_lengths)
+    return desc
+
+
+def _check_rowmajor(name, codes, M, n_tokens):
+    if codes.dim() != 4 or codes.shape[3] != M:
+        raise RuntimeError(f"pq_decode_attn: {name} must be (bs, nh_k, T, M)")
+    if codes.shape[2] and (codes.stride(3) != 1 or codes.stride(2) != M):
+        raise RuntimeError(f"pq_decode_attn: {name} rows must be dense (stride M)")
+    if n_tokens > codes.shape[2]:
+        raise RuntimeError(f"pq_decode_attn: n_tokens exceeds {name}")
+
+
+def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor, k_prep: torch.Tensor,
+                   v_prep: torch.Tensor, k_res: torch.Tensor, v_res: torch.Tensor, r: int, *, M: int, C: int,
+                   n_tokens: Optional[int] = None, resid_start: int = 0,
+                   k_page_ids: Optional[torch.Tensor] = None, v_page_ids: Optional[torch.Tensor] = None,
+                   page_size: int = 0, out: Optional[torch.Tensor] = None,
+                   dev_lengths: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One fused launch: score/softmax/value-reconstruct over the code store + residual window + merge.
+
+    A side is row-major when its page ids are None: codes (bs, nh_k, T_cap, M) u8 — the reference's
+    10-arg call (Interface.template.cu:26-38).  Paged: K pool (n_pool, page_size, M), V pool
+    (n_pool, M, page_size), page ids (bs, nh_k, n_pages_cap) int32/int64 (paged_pq_utils.py:621-635 passes
+    row-major K with paged V).
+    """
+    _need_cuda(q, k_codes, v_codes, k_prep, v_prep, k_res, v_res, k_page_ids, v_page_ids, out, dev_lengths)
+    if q.dtype != torch.float16 or k_res.dtype != torch.float16 or v_res.dtype != torch.float16:
+        raise RuntimeError("pq_decode_attn: q and residuals must be fp16")
+    if k_codes.dtype != torch.uint8 or v_codes.dtype != torch.uint8:
+        raise RuntimeError("pq_decode_attn: codes must be uint8")
+    if q.dim() != 4 or q.shape[2] != 1 or not q.is_contiguous():
+        raise RuntimeError("pq_decode_attn: q must be contiguous (bs, nh, 1, d)")
+    if (k_res.shape != v_res.shape or k_res.stride() != v_res.stride() or k_res.stride(3) != 1
+            or k_res.stride(2) != k_res.shape[3]):
+        raise RuntimeError("pq_decode_attn: residual buffers must share shape/strides with dense rows")
+    nh_k = k_res.shape[1]
+    k_paged, v_paged = k_page_ids is not None, v_page_ids is not None
+    n_pages_cap, ids64 = 0, False
+    for ids in (k_page_ids, v_page_ids):
+        if ids is None:
+            continue
+        if ids.dtype not in (torch.int32, torch.int64) or not ids.is_contiguous() or ids.dim() != 3:
+            raise RuntimeError("pq_decode_attn: page ids must be contiguous int32/int64 (bs, nh_k, n_pages)")
+        if n_pages_cap and (ids.shape[2] != n_pages_cap or (ids.dtype == torch.int64) != ids64):
+            raise RuntimeError("pq_decode_attn: K and V page ids must agree in dtype and length")
+        n_pages_cap, ids64 = ids.shape[2], ids.dtype == torch.int64
+    if n_tokens is None:
+        if k_paged and v_paged:
+            raise RuntimeError("pq_decode_attn: fully paged mode needs n_tokens")
+        n_tokens = (v_codes if k_paged else k_codes).shape[2]
+    if k_paged:
+        if not k_codes.is_contiguous():
+            raise RuntimeError("pq_decode_attn: K page pool must be contiguous")
+    else:
+        _check_rowmajor("key_codes", k_codes, M, n_tokens)
+    if v_paged:
+        if not v_codes.is_contiguous():
+            raise RuntimeError("pq_decode_attn: V page pool must be contiguous")
+    else:
+        _check_rowmajor("value_codes", v_codes, M, n_tokens)
+    desc = make_attn_desc(q, k_res, nh_k=nh_k, M=M, C=C, n_tokens=n_tokens, r=r, resid_start=resid_start,
+                          k_paged=k_paged, v_paged=v_paged, page_size=page_size, n_pages_cap=n_pages_cap,
+                          page_ids_i64=ids64, k_codes=k_codes, v_codes=v_codes, dev_lengths=dev_lengths)
+    if out is None:
+        out = torch.empty_like(q)
+    ws = workspace if workspace is not None else attn_workspace(desc, q.device)
+    lib = L.load()
+    L.check(lib.million_pq_decode_attn(ctypes.byref(desc), q.data_ptr(), _ptr(k_codes), _ptr(v_codes),
+                                       _ptr(k_page_ids), _ptr(v_page_ids),
+                                       k_prep.data_ptr(), v_prep.data_ptr(), k_res.data_ptr(), v_res.data_ptr(),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "million_pq_decode_attn")
+    return out
+
+
+def residual_append(k_new: torch.Tensor, v_new: torch.Tensor, k_res: torch.Tensor, v_res: torch.Tensor, r: int,
+                    resid_start: int = 0, dev_lengths: Optional[torch.Tensor] = None) -> None:
+    """Write the new token's K/V rows into the residual window (replaces pq_utils.py:304-312)."""
+    _need_cuda(k_new, v_new, k_res, v_res, dev_lengths)
+    bs, nhk, cap, d = k_res.shape
+    if k_new.shape != (bs, nhk, 1, d) or v_new.shape != (bs, nhk, 1, d):
+        raise RuntimeError("residual_append: new rows must be (bs, nh_k, 1, d)")
+    k_new, v_new = k_new.contiguous(), v_new.contiguous()
+    lib = L.load()
+    L.check(lib.million_residual_append(k_new.data_ptr(), v_new.data_ptr(), k_res.data_ptr(), v_res.data_ptr(),
+                                        bs, nhk, d, cap, k_res.stride(0), k_res.stride(1), r, resid_start,
+                                        _ptr(dev_lengths), _stream()), "million_residual_append")
+
+
+def set_force_generic(on: bool) -> None:
+    L.load().million_set_force_generic(int(on))
+
+
+def attn_kernel_kind(desc: L.AttnDesc) -> int:
+    return L.load().million_attn_kernel_kind(ctypes.byref(desc))

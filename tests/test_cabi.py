@@ -1,0 +1,89 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/million_hip.h declares (no compute calls without a GPU); argument validation that
+happens before any launch; the `bindings` module exports the reference's names."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from million_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from million_amd import _lib
+    hdr = (ROOT / "include" / "million_hip.h").read_text()
+    declared = set(re.findall(r"\b(million_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"million_stream_t"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.million_version() == 1
+
+
+def test_struct_sizes_match_header(lib):
+    """ctypes mirrors must have the C layout: compile a tiny C program against the header."""
+    import subprocess, tempfile
+    from million_amd import _lib
+    src = '#include "million_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", sizeof(million_encode_desc), sizeof(million_attn_desc));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "a.c").write_text(src)
+        subprocess.check_call(["gcc", "-std=c11", "-I", str(ROOT / "include"), "-o", f"{td}/a", f"{td}/a.c"])
+        enc, attn = map(int, subprocess.check_output([f"{td}/a"]).split())
+    assert enc == ctypes.sizeof(_lib.EncodeDesc)
+    assert attn == ctypes.sizeof(_lib.AttnDesc)
+
+
+def test_argument_validation_without_gpu(lib):
+    from million_amd import _lib
+    d = _lib.AttnDesc()
+    d.struct_size = 3
+    rc = lib.million_pq_decode_attn(ctypes.byref(d), *([None] * 11), 0, None)
+    assert rc == -3 and b"struct_size" in lib.million_last_error()
+    d.struct_size = ctypes.sizeof(_lib.AttnDesc)
+    d.bs, d.nh, d.nh_k, d.d, d.M, d.C = 1, 32, 8, 128, 64, 256
+    d.n_tokens, d.r, d.resid_cap = 10, 200, 128
+    assert lib.million_pq_decode_attn(ctypes.byref(d), *([None] * 11), 0, None) == -3
+    assert b"r=200" in lib.million_last_error()
+    d.r = 17
+    assert lib.million_pq_decode_attn(ctypes.byref(d), *([None] * 11), 0, None) == -3   # null pointers
+    d.nh = 33
+    assert lib.million_pq_decode_attn(ctypes.byref(d), *([None] * 11), 0, None) == -1
+    assert lib.million_attn_workspace_bytes(ctypes.byref(d)) == 0
+    d.nh = 32
+    assert lib.million_attn_workspace_bytes(ctypes.byref(d)) > 8 * 65 * 4 * 130 * 4
+    e = _lib.EncodeDesc()
+    assert lib.million_pq_encode(ctypes.byref(e), None, None, None, None, None) == -3
+    assert lib.million_prepared_cents_bytes(64, 256, 2) == 2 * 64 * 256 * 2 * 2
+
+
+def test_bindings_exports_reference_names():
+    import bindings
+    # the 240 names the reference generates (setup.py:26-54) ...
+    for Ns in (2, 4, 8, 16, 32):
+        for d in (64, 128):
+            for M in (16, 32, 64):
+                for C in (128, 256):
+                    for fam in ("allocated_buffer", "allocated_paged_buffer", "allocated_paged_split_qkv_buffer",
+                                "allocated_paged_lastblock_sync_buffer"):
+                        assert callable(getattr(bindings, f"flash_decoding_{fam}_f16u8_Ns{Ns}Lt{d}d{d}M{M}C{C}"))
+    # ... plus Ns1 (l2Ns returns 1 for l <= 64), the 13-arg paged call and the encode entry
+    assert callable(bindings.flash_decoding_allocated_buffer_f16u8_Ns1Lt128d128M64C256)
+    assert callable(bindings.flash_decoding_paged_v_f16u8_Ns32Lt128d128M64C256)
+    assert callable(bindings.pq_encode_f16u8_d128M64C256)
+    assert "flash_decoding_paged_v_f16u8_Ns32Lt128d128M64C256" in dir(bindings)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from million_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.pq_encode(torch.zeros(1, 1, 4, 128, dtype=torch.float16), torch.zeros(64, 256, 2, dtype=torch.float16))

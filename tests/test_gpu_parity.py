@@ -1,0 +1,256 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path through the C ABI vs the CPU oracle.
+
+Bars (BASELINE.md 2 / SURVEY.md 8c): uint8 codes bit-exact with oracle/pq_oracle.c:pq_encode_direct;
+fp16 attention output within 1e-3 relative (rel-L2) and mean-abs < 1e-3 (the reference's own bar,
+scripts/utils/pq_utils.py:374-379) of the fp64 oracle.  Nothing here reads /root/reference.
+"""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3       # ||out - gold|| / ||gold||   (north_star: "fp16 attention output within 1e-3 rel")
+MEAN_ABS_TOL = 1e-3  # reference bar, pq_utils.py:374-379
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from million_amd import ops, _lib
+    _lib.load()   # fails loudly if libmillion_hip.so is missing
+    return torch, ops
+
+
+def _dev(torch, c):
+    return {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+
+
+def _check(out, gold, what=""):
+    out = out.astype(np.float64)
+    gold = np.asarray(gold, dtype=np.float64)
+    assert np.isfinite(out).all(), what
+    rel = np.linalg.norm(out - gold) / max(np.linalg.norm(gold), 1e-30)
+    mae = np.abs(out - gold).mean()
+    assert rel < REL_TOL and mae < MEAN_ABS_TOL, f"{what}: rel={rel:.3e} mean_abs={mae:.3e}"
+    return rel, mae
+
+
+def _run_rowmajor(torch, ops, c, M, C):
+    t = _dev(torch, c)
+    kp = ops.prepare_cents(t["k_cents"], cache=False)
+    vp = ops.prepare_cents(t["v_cents"], cache=False)
+    out = ops.pq_decode_attn(t["q"], t["k_codes"], t["v_codes"], kp, vp, t["k_res"], t["v_res"], c["r"], M=M, C=C)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _run_paged(torch, ops, oracle, c, M, C, ps, k_paged=True, shuffle=True, i64=False):
+    t = _dev(torch, c)
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    if shuffle and vpool.shape[0] > 1:      # physical page order must not matter
+        perm = np.random.RandomState(5).permutation(vpool.shape[0])
+        inv = np.argsort(perm)
+        vpool, kpool, ids = vpool[perm], kpool[perm], inv[ids]
+    T = c["k_codes"].shape[2]
+    ids_t = torch.from_numpy(ids.astype(np.int64 if i64 else np.int32)).cuda()
+    kp = ops.prepare_cents(t["k_cents"], cache=False)
+    vp = ops.prepare_cents(t["v_cents"], cache=False)
+    out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda() if k_paged else t["k_codes"],
+                             torch.from_numpy(vpool).cuda(), kp, vp, t["k_res"], t["v_res"], c["r"], M=M, C=C,
+                             n_tokens=T, k_page_ids=ids_t if k_paged else None, v_page_ids=ids_t, page_size=ps)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+# ---------------------------------------------------------------- encode: bit-exact -----------------
+@pytest.mark.parametrize("case", synth.GOLDEN_ENCODE, ids=[c[0] for c in synth.GOLDEN_ENCODE])
+def test_encode_bit_exact_small(case, env, oracle):
+    torch, ops = env
+    name, seed, bs, nhk, n, d, M, C = case
+    c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+    codes = ops.pq_encode(torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["cents"]).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(codes, oracle.pq_encode(c["X"], c["cents"]))
+
+
+def test_encode_bit_exact_cfg1_hash(env, oracle, golden_dir):
+    """BASELINE config 1 size (1,8,4096,128): SHA-256 of the codes == committed oracle hash."""
+    torch, ops = env
+    man = json.loads((golden_dir / "manifest.json").read_text())["encode_big"]
+    name, seed, bs, nhk, n, d, M, C = synth.GOLDEN_ENCODE_BIG
+    c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+    codes = ops.pq_encode(torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["cents"]).cuda()).cpu().numpy()
+    assert hashlib.sha256(codes.tobytes()).hexdigest() == man["sha256_direct_oracle_codes"]
+
+
+def test_encode_ties_and_layouts(env, oracle):
+    torch, ops = env
+    from million_amd import _lib as L
+    rs = np.random.RandomState(11)
+    M, C, d = 64, 256, 128
+    cents = rs.standard_normal((M, C, 2)).astype(np.float16)
+    cents[:, 200] = cents[:, 7]          # exact duplicates: lower index must win
+    X = rs.standard_normal((2, 3, 150, d)).astype(np.float16)
+    X[0, 0, :10] = cents[:, 7].reshape(-1)      # rows sitting exactly on the duplicated centroid
+    gold = oracle.pq_encode(X, cents)
+    Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(cents).cuda()
+    assert (gold[0, 0, :10] == 7).all()
+    np.testing.assert_array_equal(ops.pq_encode(Xd, cd).cpu().numpy(), gold)
+    # paged destinations: K pages row-major, V pages transposed, written at a token offset
+    ps, t0 = 64, 64
+    n_pages = (t0 + 150 + ps - 1) // ps
+    ids = torch.arange(2 * 3 * n_pages, dtype=torch.int32).reshape(2, 3, n_pages).flip(2).contiguous().cuda()
+    kpool = torch.zeros(2 * 3 * n_pages, ps, M, dtype=torch.uint8).cuda()
+    vpool = torch.zeros(2 * 3 * n_pages, M, ps, dtype=torch.uint8).cuda()
+    ops.pq_encode_into(Xd, cd, kpool, layout=L.MILLION_CODES_KPAGES, token_start=t0, page_ids=ids, page_size=ps)
+    ops.pq_encode_into(Xd, cd, vpool, layout=L.MILLION_CODES_VPAGES, token_start=t0, page_ids=ids, page_size=ps)
+    kp, vp, idn = kpool.cpu().numpy(), vpool.cpu().numpy(), ids.cpu().numpy()
+    for b in range(2):
+        for h in range(3):
+            for t in range(150):
+                tok = t0 + t
+                pid = idn[b, h, tok // ps]
+                assert (kp[pid, tok % ps] == gold[b, h, t]).all()
+                assert (vp[pid, :, tok % ps] == gold[b, h, t]).all()
+    # ring-buffer source rows + strided view (residual window flush)
+    buf = torch.zeros(2, 3, 128, d, dtype=torch.float16).cuda()
+    rows = (np.arange(64) + 100) % 128
+    buf[:, :, rows] = Xd[:, :, :64]
+    out = torch.zeros(2, 3, 64, M, dtype=torch.uint8).cuda()
+    ops.pq_encode_into(buf, cd, out, n=64, x_row_start=100, x_row_mod=128)
+    np.testing.assert_array_equal(out.cpu().numpy(), gold[:, :, :64])
+
+
+# ---------------------------------------------------------------- attention -------------------------
+@pytest.mark.parametrize("case", synth.GOLDEN_ATTN, ids=[c[0] for c in synth.GOLDEN_ATTN])
+@pytest.mark.parametrize("force_generic", [False, True], ids=["auto", "generic"])
+def test_attn_golden_rowmajor(case, force_generic, env, oracle, golden_dir):
+    torch, ops = env
+    name, seed, bs, nh, nhk, d, M, C, T, r = case
+    c = synth.attn_case(seed, bs, nh, nhk, d, M, C, T, r)
+    ops.set_force_generic(force_generic)
+    try:
+        out = _run_rowmajor(torch, ops, c, M, C)
+    finally:
+        ops.set_force_generic(False)
+    gold = oracle.decode_attn(**c)
+    _check(out, gold, name)
+    fix = np.load(golden_dir / f"attn_{name}.npz")["out"]       # the reference's own formula, torch fp32
+    _check(out, fix, name + " vs fixture")
+
+
+@pytest.mark.parametrize("case", [c for c in synth.GOLDEN_ATTN if c[8] > 0 and c[5] == 128],
+                         ids=[c[0] for c in synth.GOLDEN_ATTN if c[8] > 0 and c[5] == 128])
+@pytest.mark.parametrize("ps", [32, 64, 128])
+def test_attn_golden_paged(case, ps, env, oracle):
+    torch, ops = env
+    name, seed, bs, nh, nhk, d, M, C, T, r = case
+    c = synth.attn_case(seed, bs, nh, nhk, d, M, C, T, r)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, M, C, ps), gold, f"{name} paged ps={ps}")
+    # the reference's 13-arg layout: row-major K, paged V, int64 page ids
+    _check(_run_paged(torch, ops, oracle, c, M, C, ps, k_paged=False, i64=True), gold, f"{name} mixed ps={ps}")
+
+
+@pytest.mark.parametrize("T,r,nh,nhk,M", [(4096, 17, 8, 8, 64), (4097, 128, 32, 8, 64), (5000, 1, 8, 2, 32),
+                                          (33, 0, 4, 4, 64), (0, 128, 32, 8, 64), (2048 + 31, 64, 16, 8, 64)])
+def test_attn_random_shapes(T, r, nh, nhk, M, env, oracle):
+    torch, ops = env
+    c = synth.attn_case(1000 + T + r, 1, nh, nhk, 128, M, 256, T, r)
+    gold = oracle.decode_attn(**c)
+    _check(_run_rowmajor(torch, ops, c, M, 256), gold, "rowmajor")
+    if T:
+        _check(_run_paged(torch, ops, oracle, c, M, 256, 64), gold, "paged")
+
+
+def test_attn_resid_ring_and_repeat_calls(env, oracle):
+    """Residual ring buffer (resid_start > 0), reuse of the workspace across calls, batch > 1."""
+    torch, ops = env
+    c = synth.attn_case(77, 2, 8, 2, 128, 64, 256, 700, 50)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    gold = oracle.decode_attn(**c)
+    start = 100
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    for _ in range(3):
+        out = ops.pq_decode_attn(t["q"], t["k_codes"], t["v_codes"], kp, vp, kr, vr, c["r"], M=64, C=256,
+                                 resid_start=start)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), gold, "ring")
+
+
+def test_attn_peaked_softmax_forces_rescale(env, oracle):
+    """One key matches the query strongly late in the sequence, so the running max jumps mid-stream
+    (cdna_hip_programming.md rule 26: a data-dependent rescale branch needs an input that forces it)."""
+    torch, ops = env
+    c = synth.attn_case(88, 1, 8, 2, 128, 64, 256, 3000, 9)
+    # make code 0 of every subspace point along q of head 0 (large positive score), and plant it at token 2500
+    kc = c["k_cents"].astype(np.float32)
+    q0 = c["q"][0, 0, 0].astype(np.float32).reshape(64, 2)
+    kc[:, 0, :] = 3.0 * q0
+    c["k_cents"] = kc.astype(np.float16)
+    c["k_codes"][0, 0, 2500, :] = 0
+    c["k_codes"][0, 0, 10, :32] = 0
+    gold = oracle.decode_attn(**c)
+    _check(_run_rowmajor(torch, ops, c, 64, 256), gold, "peaked rowmajor")
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, "peaked paged")
+
+
+def test_bindings_module_dropin(env, oracle):
+    """The reference's call sequence (pq_utils.py:61-94; test_kernel.py:45-69) through `bindings`."""
+    torch, ops = env
+    import bindings
+    bs, nh, d, M, C, T, r, Ns = 1, 32, 128, 64, 256, 1000, 17, 16
+    c = synth.attn_case(5, bs, nh, nh, d, M, C, T, r)
+    t = _dev(torch, c)
+    fn = getattr(__import__("bindings"), f"flash_decoding_allocated_buffer_f16u8_Ns{Ns}Lt{d}d{d}M{M}C{C}")
+    po = torch.empty(bs, nh, Ns + 1, d, dtype=torch.float16, device="cuda")
+    pl = torch.empty(bs, nh, Ns + 1, dtype=torch.float16, device="cuda")
+    out = fn(t["q"], t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"], t["v_res"], r, po, pl)
+    assert out.shape == (bs, nh, 1, d) and out.dtype == torch.float16
+    gold = oracle.decode_attn(**c)
+    _check(out.cpu().numpy(), gold, "bindings 10-arg")
+    # residual views sliced to r rows (paged_pq_utils.py:421)
+    out2 = fn(t["q"], t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"][:, :, :r], t["v_res"][:, :, :r], r, po, pl)
+    _check(out2.cpu().numpy(), gold, "bindings residual views")
+    # 13-arg paged call (paged_pq_utils.py:621-635)
+    ps = 64
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    pfn = getattr(bindings, f"flash_decoding_paged_v_f16u8_Ns{Ns}Lt128d{d}M{M}C{C}")
+    out3 = pfn(t["q"], t["k_codes"], t["k_cents"], t["k_res"][:, :, :r], torch.from_numpy(ids).cuda(),
+               torch.from_numpy(vpool).cuda(), t["v_cents"], t["v_res"][:, :, :r], r, ids.shape[2], ps, po, pl)
+    _check(out3.cpu().numpy(), gold, "bindings 13-arg")
+    enc = getattr(bindings, f"pq_encode_f16u8_d{d}M{M}C{C}")
+    e = synth.encode_case(9, 1, 2, 70, d, M, C)
+    np.testing.assert_array_equal(enc(torch.from_numpy(e["X"]).cuda(), torch.from_numpy(e["cents"]).cuda()).cpu().numpy(),
+                                  oracle.pq_encode(e["X"], e["cents"]))
+    with pytest.raises(RuntimeError):
+        fn(t["q"].float(), t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"], t["v_res"], r, po, pl)
+
+
+def test_residual_append_and_dev_lengths(env, oracle):
+    torch, ops = env
+    c = synth.attn_case(31, 2, 8, 2, 128, 64, 256, 300, 20)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    rs = np.random.RandomState(1)
+    k_new = rs.standard_normal((2, 2, 1, 128)).astype(np.float16)
+    v_new = rs.standard_normal((2, 2, 1, 128)).astype(np.float16)
+    lengths = torch.tensor([[300, 20, 0, 0], [300, 20, 0, 0]], dtype=torch.int32, device="cuda")
+    kr, vr = t["k_res"].clone(), t["v_res"].clone()
+    ops.residual_append(torch.from_numpy(k_new).cuda(), torch.from_numpy(v_new).cuda(), kr, vr, 0, 0, dev_lengths=lengths)
+    out = ops.pq_decode_attn(t["q"], t["k_codes"], t["v_codes"], kp, vp, kr, vr, 0, M=64, C=256, dev_lengths=lengths)
+    torch.cuda.synchronize()
+    assert lengths.cpu().numpy()[:, 1].tolist() == [21, 21]
+    c2 = dict(c)
+    c2["k_res"] = c["k_res"].copy(); c2["v_res"] = c["v_res"].copy()
+    c2["k_res"][:, :, 20] = k_new[:, :, 0]; c2["v_res"][:, :, 20] = v_new[:, :, 0]
+    c2["r"] = 21
+    _check(out.cpu().numpy(), oracle.decode_attn(**c2), "append + device lengths")
