@@ -83,6 +83,9 @@ typedef struct {
     int64_t dst_stride_b, dst_stride_h;   /* bytes; ROWMAJOR only (row stride is M bytes) */
     int32_t page_size;            /* KPAGES / VPAGES */
     int32_t n_pages_cap;          /* page_ids is (bs, nh_k, n_pages_cap) int32 */
+    const int32_t *dev_lengths;   /* optional device array (bs, 4) = {n_tokens, r, resid_start, 0}: when set,
+                                     dst_token_start := n_tokens and x_row_start := resid_start are read on the
+                                     device (flush of the residual window inside a replayed hipGraph) */
 } million_encode_desc;
 
 int million_pq_encode(const million_encode_desc *desc, const void *x, const void *cents /* (M,C,d_m) fp16 */,
@@ -160,6 +163,11 @@ int million_residual_append(const void *k_new, const void *v_new, void *k_resid,
                             int bs, int nh_k, int d, int resid_cap,
                             int64_t resid_stride_b, int64_t resid_stride_h,
                             int r, int resid_start, int32_t *dev_lengths, million_stream_t stream);
+
+/* After a flush of `n_flushed` residual rows into the code store (reference: flush_to_pages,
+ * paged_pq_utils.py:181-208 / DynamicPQCache.decoding, pq_utils.py:297-301) advance the device-resident
+ * lengths: n_tokens += n_flushed, r -= n_flushed, resid_start = (resid_start + n_flushed) % resid_cap. */
+int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int resid_cap, million_stream_t stream);
 
 #ifdef __cplusplus
 }

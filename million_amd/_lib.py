@@ -21,7 +21,7 @@ class EncodeDesc(ctypes.Structure):
                 ("x_row_start", c_i32), ("x_row_mod", c_i32),
                 ("dst_layout", c_i32), ("dst_token_start", c_i32),
                 ("dst_stride_b", c_i64), ("dst_stride_h", c_i64),
-                ("page_size", c_i32), ("n_pages_cap", c_i32)]
+                ("page_size", c_i32), ("n_pages_cap", c_i32), ("dev_lengths", c_vp)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -48,6 +48,7 @@ SYMBOLS = {
                                        c_vp, c_vp, c_vp, c_sz, c_vp]),
     "million_attn_kernel_kind": (c_i32, [ctypes.POINTER(AttnDesc)]),
     "million_set_force_generic": (None, [c_i32]),
+    "million_lengths_advance": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "million_residual_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64,
                                         c_i32, c_i32, c_vp, c_vp]),
 }

@@ -135,6 +135,7 @@ struct EncParams {
     int layout, tok0;
     long long dsb, dsh;
     int page_size, n_pages_cap;
+    const int *dev_lengths;
 };
 
 // host-side launchers (defined in the .hip files)

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
     if (m >= p.M) return;
     const bool valid = t < p.n;
     const int tc = valid ? t : p.n - 1;
-    const int xrow = p.xrow_mod > 0 ? (p.xrow_start + tc) % p.xrow_mod : tc;
+    int tok0 = p.tok0, xrow_start = p.xrow_start;
+    if (p.dev_lengths) { tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2]; }
+    const int xrow = p.xrow_mod > 0 ? (xrow_start + tc) % p.xrow_mod : tc;
     const f16 *xp = p.x + b * p.xsb + hk * p.xsh + (long long)xrow * p.xsn + m * DM;
     float x[DM];
 #pragma unroll
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
         if (acc < best) { best = acc; best_c = c; }
     }
     if (!valid) return;
-    const int tok = p.tok0 + t;
+    const int tok = tok0 + t;
     if (p.layout == MILLION_CODES_ROWMAJOR) {
         p.dst[b * p.dsb + hk * p.dsh + (long long)tok * p.M + m] = (uint8_t)best_c;
     } else {

@@ -61,6 +61,14 @@ __global__ void residual_append_kernel(const f16 *__restrict__ k_new, const f16 
     }
 }
 
+__global__ void lengths_advance_kernel(int *dl, int bs, int n, int cap) {
+    for (int b = threadIdx.x; b < bs; b += blockDim.x) {
+        dl[b * 4 + 0] += n;
+        dl[b * 4 + 1] -= n;
+        dl[b * 4 + 2] = (dl[b * 4 + 2] + n) % cap;
+    }
+}
+
 static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     if (!desc || desc->struct_size != sizeof(million_attn_desc)) { set_error("attn: bad desc / struct_size"); return MILLION_ERR_ARG; }
     memset(&p, 0, sizeof(p));
@@ -152,10 +160,11 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
     p.layout = desc->dst_layout; p.tok0 = desc->dst_token_start;
     p.dsb = desc->dst_stride_b; p.dsh = desc->dst_stride_h;
     p.page_size = desc->page_size; p.n_pages_cap = desc->n_pages_cap;
+    p.dev_lengths = desc->dev_lengths;
     if (p.layout != MILLION_CODES_ROWMAJOR) {
         if (p.layout != MILLION_CODES_KPAGES && p.layout != MILLION_CODES_VPAGES) { set_error("encode: dst_layout=%d", p.layout); return MILLION_ERR_ARG; }
         if (!page_ids || p.page_size <= 0) { set_error("encode: paged destination needs page_ids and page_size"); return MILLION_ERR_ARG; }
-        if ((long long)p.n_pages_cap * p.page_size < (long long)p.tok0 + p.n) { set_error("encode: page table too short"); return MILLION_ERR_ARG; }
+        if (!p.dev_lengths && (long long)p.n_pages_cap * p.page_size < (long long)p.tok0 + p.n) { set_error("encode: page table too short"); return MILLION_ERR_ARG; }
     }
     if (p.tok0 < 0) { set_error("encode: dst_token_start=%d", p.tok0); return MILLION_ERR_ARG; }
     return launch_encode(p, (hipStream_t)stream);
@@ -231,6 +240,14 @@ int million_residual_append(const void *k_new, const void *v_new, void *k_resid,
                        (long long)resid_stride_b, (long long)resid_stride_h, r, resid_start, dev_lengths);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("residual_append launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
+int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int resid_cap, million_stream_t stream) {
+    if (!dev_lengths || bs <= 0 || resid_cap <= 0) { set_error("lengths_advance: bad argument"); return MILLION_ERR_ARG; }
+    hipLaunchKernelGGL(lengths_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_lengths, bs, n_flushed, resid_cap);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("lengths_advance launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
     return MILLION_OK;
 }
 

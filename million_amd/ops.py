@@ -56,7 +56,8 @@ def prepare_cents(cents: torch.Tensor, cache: bool = True) -> torch.Tensor:
 
 def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, layout: int = L.MILLION_CODES_ROWMAJOR,
                    token_start: int = 0, n: Optional[int] = None, page_ids: Optional[torch.Tensor] = None,
-                   page_size: int = 0, x_row_start: int = 0, x_row_mod: int = 0) -> None:
+                   page_size: int = 0, x_row_start: int = 0, x_row_mod: int = 0,
+                   dev_lengths: Optional[torch.Tensor] = None) -> None:
     """Encode rows of X (bs, nh_k, n_rows, d) fp16 and write the codes into `dst` in their final layout."""
     _need_cuda(X, cents, dst, page_ids)
     if X.dtype != torch.float16 or cents.dtype != torch.float16 or dst.dtype != torch.uint8:
@@ -85,6 +86,7 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
         if not dst.is_contiguous():
             raise RuntimeError("pq_encode: page pool must be contiguous")
         desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
+    desc.dev_lengths = _ptr(dev_lengths)
     lib = L.load()
     L.check(lib.million_pq_encode(ctypes.byref(desc), X.data_ptr(), cents.data_ptr(), dst.data_ptr(),
                                   _ptr(page_ids), _stream()), "million_pq_encode")
@@ -214,6 +216,12 @@ def residual_append(k_new: torch.Tensor, v_new: torch.Tensor, k_res: torch.Tenso
     L.check(lib.million_residual_append(k_new.data_ptr(), v_new.data_ptr(), k_res.data_ptr(), v_res.data_ptr(),
                                         bs, nhk, d, cap, k_res.stride(0), k_res.stride(1), r, resid_start,
                                         _ptr(dev_lengths), _stream()), "million_residual_append")
+
+
+def lengths_advance(dev_lengths: torch.Tensor, n_flushed: int, resid_cap: int) -> None:
+    _need_cuda(dev_lengths)
+    L.check(L.load().million_lengths_advance(dev_lengths.data_ptr(), dev_lengths.shape[0], n_flushed, resid_cap,
+                                             _stream()), "million_lengths_advance")
 
 
 def set_force_generic(on: bool) -> None:

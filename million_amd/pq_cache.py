@@ -1,0 +1,424 @@
+"""Host-side mirror of the reference's KV-cache objects for the PQ-KV hot path.
+
+Same names, constructor arguments and method meaning as the reference (scripts/utils/pq_utils.py:98-408
+DynamicPQCache, scripts/utils/paged_pq_utils.py:10-397 PagedPQCache, scripts/utils/
+dynamic_paged_pq_utils.py:10-321 PageManager, pq_utils.py:8-96 l2Ns / KernelRegistry), re-designed for
+MI355X:
+
+  * storage is PREALLOCATED (288 GB HBM): no torch.cat growth (pq_utils.py:145-146 reallocates O(T) per
+    flush), no per-step pad/transpose of all V codes (paged_pq_utils.py:464-486);
+  * the encode kernel writes codes straight into their final place (row-major store, K pages,
+    transposed V pages);
+  * the residual window is a ring buffer: a flush advances `resid_start`, nothing is shifted
+    (paged_pq_utils.py:188-204 clones and copies the survivors);
+  * lengths live on the device as well (int32 (bs, 4) = {n_tokens, r, resid_start, 0}) so a whole decode
+    step can be captured in one hipGraph and replayed while the lengths change;
+  * no global singletons (reference: metaclass Singleton), no exit(), no silent fallbacks: errors raise.
+
+[QUIRK]s of the reference that are NOT reproduced: seen_tokens double counting on flush
+(paged_pq_utils.py:208), page pool built from batch 0 / head 0 only (:457), causal mask with one query
+row in the fallback (:888), the nested try/except fallbacks.
+"""
+from __future__ import annotations
+
+import heapq
+from typing import Dict, List, Optional, Set
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def l2Ns(l: int) -> int:
+    """Split-count heuristic of the reference (pq_utils.py:8-22).  Only selects the binding NAME here:
+    the HIP kernel sizes its own split count from the CU count."""
+    if l > 2048:
+        return 32
+    if l > 256:
+        return 16
+    if l > 128:
+        return 4
+    if l > 64:
+        return 2
+    return 1
+
+
+def scalarTypeToStr(scalar_t) -> str:
+    if scalar_t == torch.float16:
+        return "f16"
+    if scalar_t == torch.float32:
+        return "f32"
+    raise ValueError(f"Unknown scalar type: {scalar_t}")
+
+
+def nbits2dtype(nbits: int):
+    """pq_utils.py:542-552."""
+    if nbits <= 8:
+        return torch.uint8
+    if nbits <= 16:
+        return torch.uint16
+    if nbits <= 32:
+        return torch.uint32
+    if nbits <= 64:
+        return torch.uint64
+    raise ValueError("nbits must be <= 64")
+
+
+class KernelRegistry:
+    """pq_utils.py:32-96: resolves `bindings.flash_decoding_allocated_buffer_{T}u8_Ns{Ns}Lt{d}d{d}M{M}C{C}`
+    by name and owns the (unused by the HIP path, but part of the signature) partial buffers."""
+
+    def __init__(self, *, M=64, d=128, nbits=8, nh=32, scalar_t=torch.float16, device="cuda"):
+        self.kernels, self.partial_out_buffers, self.partial_lse_buffers = {}, {}, {}
+        self.M, self.d, self.nbits, self.nh, self.scalar_t, self.device = M, d, nbits, nh, scalar_t, device
+
+    def get_kernel(self, l=4096):
+        Ns = l2Ns(l)
+        if Ns not in self.kernels:
+            self.kernels[Ns] = self.get_custom_kernel_with_allocated_buffer(l)
+        return self.kernels[Ns]
+
+    def get_custom_kernel_with_allocated_buffer(self, l=4096):
+        if self.nbits != 8:
+            raise NotImplementedError("Only uint8 code type is supported for now")
+        Ns = l2Ns(l)
+        fname = (f"flash_decoding_allocated_buffer_{scalarTypeToStr(self.scalar_t)}u8_"
+                 f"Ns{Ns}Lt{self.d}d{self.d}M{self.M}C{2 ** self.nbits}")
+        func = getattr(__import__("bindings"), fname)
+        po = torch.empty(1, self.nh, Ns + 1, self.d, dtype=self.scalar_t, device=self.device)
+        pl = torch.empty(1, self.nh, Ns + 1, dtype=self.scalar_t, device=self.device)
+        self.partial_out_buffers[Ns], self.partial_lse_buffers[Ns] = po, pl
+
+        def flash_decoding(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals, r):
+            return func(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals, r, po, pl)
+
+        return flash_decoding
+
+
+class PageManager:
+    """Free-list page allocator with the semantics of dynamic_paged_pq_utils.py:10-321 (allocate_page,
+    allocate_pages, free_page, growth by 1.5x capped by max_pages, stats) over ids only — the pools
+    themselves are preallocated tensors owned by the cache, so growth never copies pool memory here."""
+
+    def __init__(self, page_size: int = 64, initial_pages: int = 100, max_pages: Optional[int] = None, M: int = 64):
+        if max_pages is not None and initial_pages > max_pages:
+            initial_pages = max_pages
+        self.page_size, self.M = page_size, M
+        self.initial_pages, self.max_pages = initial_pages, max_pages
+        self.current_active_pages = initial_pages
+        self.free_pages: Set[int] = set(range(initial_pages))
+        self._heap: List[int] = list(range(initial_pages))     # min-heap over free ids: lowest id first
+        self.allocated_pages: Dict[int, Dict] = {}
+        self.total_allocations = self.page_reuse_count = self.total_expansions = 0
+        self._ever_used: Set[int] = set()
+
+    def _expand_page_pool(self, additional_pages: Optional[int] = None):
+        if additional_pages is None:
+            additional_pages = max(self.current_active_pages // 2, 50)      # :80
+        if self.max_pages is not None:
+            room = self.max_pages - self.current_active_pages
+            if room <= 0:
+                raise RuntimeError(f"Cannot expand page pool: reached max_pages limit {self.max_pages}")
+            additional_pages = min(additional_pages, room)
+        new = self.current_active_pages + additional_pages
+        self.free_pages.update(range(self.current_active_pages, new))
+        for i in range(self.current_active_pages, new):
+            heapq.heappush(self._heap, i)
+        self.current_active_pages = new
+        self.total_expansions += 1
+
+    def allocate_page(self) -> int:
+        if not self.free_pages:
+            try:
+                self._expand_page_pool()
+            except RuntimeError as e:
+                raise RuntimeError(f"No free pages available and cannot expand: {e}")
+        pid = heapq.heappop(self._heap)     # deterministic (the reference pops an arbitrary set element)
+        self.free_pages.remove(pid)
+        if pid in self._ever_used:
+            self.page_reuse_count += 1
+        self._ever_used.add(pid)
+        self.allocated_pages[pid] = {"allocation_count": 1}
+        self.total_allocations += 1
+        return pid
+
+    def allocate_pages(self, n: int) -> List[int]:
+        if n <= 0:
+            return []
+        if len(self.free_pages) < n:
+            self._expand_page_pool(additional_pages=n - len(self.free_pages))
+            if len(self.free_pages) < n:
+                raise RuntimeError(f"Cannot bulk-allocate {n} pages: max_pages={self.max_pages}")
+        return [self.allocate_page() for _ in range(n)]
+
+    def free_page(self, page_id: int):
+        if page_id not in self.allocated_pages:
+            return
+        del self.allocated_pages[page_id]
+        self.free_pages.add(page_id)
+        heapq.heappush(self._heap, page_id)
+
+    def get_stats(self) -> Dict:
+        return {"initial_pages": self.initial_pages, "current_active_pages": self.current_active_pages,
+                "max_pages": self.max_pages, "allocated_pages": len(self.allocated_pages),
+                "free_pages": len(self.free_pages),
+                "utilization": len(self.allocated_pages) / max(self.current_active_pages, 1),
+                "page_reuse_count": self.page_reuse_count, "total_allocations": self.total_allocations,
+                "total_expansions": self.total_expansions}
+
+
+class _CacheBase:
+    def set_cent(self, key_cent: torch.Tensor, value_cent: torch.Tensor):
+        """cent is (M, C, d//M) — one table shared by all layers and heads (pq_utils.py:149-159)."""
+        self.key_cent = key_cent.to(self.device, self.scalar_t).contiguous()
+        self.value_cent = self.key_cent if value_cent is key_cent else value_cent.to(self.device, self.scalar_t).contiguous()
+        self._kprep = ops.prepare_cents(self.key_cent, cache=False)
+        self._vprep = self._kprep if self.value_cent is self.key_cent else ops.prepare_cents(self.value_cent, cache=False)
+
+    def _prefill_attention(self, q, k, v):
+        """Prefill attention is outside the PQ hot path (reference: torch SDPA, pq_utils.py:249-260)."""
+        from torch.nn.functional import scaled_dot_product_attention as sdpa
+        G = q.size(1) // k.size(1)
+        if G > 1:
+            k, v = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
+        return sdpa(q, k, v, is_causal=True)
+
+
+class DynamicPQCache(_CacheBase):
+    """Row-major code store + residual window of Lt=d rows; flush ALL Lt rows when full
+    (reference pq_utils.py:98-328).  `max_tokens` bounds the preallocated store."""
+
+    def __init__(self, *, bs, nh, num_key_value_heads, M, layer_num, dtype=torch.uint8, nbits=8, d=128,
+                 scalar_t=torch.float16, max_tokens=32768 + 1024, device="cuda"):
+        if nbits != 8 or dtype != torch.uint8:
+            raise NotImplementedError("Only uint8 code type is supported for now")
+        self.bs, self.nh, self.num_key_value_heads, self.M, self.layer_num = bs, nh, num_key_value_heads, M, layer_num
+        self.dtype, self.nbits, self.d, self.scalar_t, self.device = dtype, nbits, d, scalar_t, torch.device(device)
+        self.C = 2 ** nbits
+        self.max_residual_length = d          # "Lt = d", pq_utils.py:110
+        self.max_tokens = (max_tokens + d - 1) // d * d
+        self.registery = KernelRegistry(M=M, d=d, nbits=nbits, nh=nh, scalar_t=scalar_t, device=device)
+        self.init_cache()
+
+    def init_cache(self):
+        z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=self.device)
+        nk, Lt = self.num_key_value_heads, self.max_residual_length
+        self._k_store = [z(self.bs, nk, self.max_tokens, self.M, dt=torch.uint8) for _ in range(self.layer_num)]
+        self._v_store = [z(self.bs, nk, self.max_tokens, self.M, dt=torch.uint8) for _ in range(self.layer_num)]
+        self.key_residual_cache = [z(self.bs, nk, Lt, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
+        self.value_residual_cache = [z(self.bs, nk, Lt, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
+        self.seen_tokens = [0] * self.layer_num
+        self.residualed_tokens = [0] * self.layer_num
+        self._T = [0] * self.layer_num
+
+    # views with the reference's shapes
+    @property
+    def key_cache(self):
+        return [s[:, :, :t] for s, t in zip(self._k_store, self._T)]
+
+    @property
+    def value_cache(self):
+        return [s[:, :, :t] for s, t in zip(self._v_store, self._T)]
+
+    def _append_codes(self, X, layer_idx, n):
+        T = self._T[layer_idx]
+        if T + n > self.max_tokens:
+            raise RuntimeError(f"DynamicPQCache: {T + n} tokens exceed max_tokens={self.max_tokens}")
+        ops.pq_encode_into(X[0], self.key_cent, self._k_store[layer_idx], token_start=T, n=n)
+        ops.pq_encode_into(X[1], self.value_cent, self._v_store[layer_idx], token_start=T, n=n)
+        self._T[layer_idx] = T + n
+
+    def prefill(self, query_states, key_states, value_states, layer_idx, distort_recent=False):
+        n = key_states.size(2)
+        self._append_codes((key_states, value_states), layer_idx, n)       # pq_utils.py:235-240
+        self.seen_tokens[layer_idx] += n
+        return self._prefill_attention(query_states, key_states, value_states)
+
+    def decoding(self, query_states, key_states, value_states, layer_idx):
+        Lt = self.max_residual_length
+        if self.residualed_tokens[layer_idx] == Lt:                        # pq_utils.py:288-302
+            self._append_codes((self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx]), layer_idx, Lt)
+            self.residualed_tokens[layer_idx] = 0
+        r = self.residualed_tokens[layer_idx]
+        ops.residual_append(key_states, value_states, self.key_residual_cache[layer_idx],
+                            self.value_residual_cache[layer_idx], r)       # :304-312
+        self.residualed_tokens[layer_idx] = r + 1
+        self.seen_tokens[layer_idx] += 1
+        return ops.pq_decode_attn(query_states, self._k_store[layer_idx], self._v_store[layer_idx], self._kprep,
+                                  self._vprep, self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx],
+                                  r + 1, M=self.M, C=self.C, n_tokens=self._T[layer_idx])   # :314-326
+
+    @property
+    def pq_cache_size(self):
+        return sum(2 * self.bs * self.num_key_value_heads * t * self.M for t in self._T)
+
+    @property
+    def residual_cache_size(self):
+        return sum(c.numel() * c.element_size() for c in self.key_residual_cache + self.value_residual_cache)
+
+
+class PagedPQCache(_CacheBase):
+    """Paged code store: K pages (page_size, M) row-major, V pages (M, page_size) transposed, a residual
+    ring of `extended_residual_size` rows; when r reaches it the OLDEST page_size rows are flushed
+    (reference paged_pq_utils.py:10-397; policy :141-153, :359-361).
+
+    One global pool per side serves all layers; page ids are handed out by a PageManager.  With
+    `preallocate=True` (default) the page table of every (layer, b, hk) is filled for `max_tokens` at
+    init, so decode steps touch no host state and are hipGraph-capturable."""
+
+    def __init__(self, *, bs, nh, num_key_value_heads, M, layer_num, dtype=torch.uint8, nbits=8, d=128,
+                 scalar_t=torch.float16, page_size=64, extended_residual_size=128, max_pages_per_layer=None,
+                 max_tokens=32768 + 1024, preallocate=True, device="cuda"):
+        if nbits != 8 or dtype != torch.uint8:
+            raise NotImplementedError("Only uint8 code type is supported for now")
+        if page_size not in (32, 64, 128):
+            raise ValueError("page_size must be 32, 64 or 128")
+        if extended_residual_size < page_size:
+            raise ValueError("extended_residual_size must be >= page_size")
+        self.bs, self.nh, self.num_key_value_heads, self.M, self.layer_num = bs, nh, num_key_value_heads, M, layer_num
+        self.dtype, self.nbits, self.d, self.scalar_t, self.device = dtype, nbits, d, scalar_t, torch.device(device)
+        self.C = 2 ** nbits
+        self.page_size, self.extended_residual_size = page_size, extended_residual_size
+        self.max_residual_length = extended_residual_size
+        self.n_pages_cap = (max_tokens + page_size - 1) // page_size
+        if max_pages_per_layer is not None:
+            self.n_pages_cap = min(self.n_pages_cap, max_pages_per_layer // max(bs * num_key_value_heads, 1))
+        self.max_tokens = self.n_pages_cap * page_size
+        self.preallocate = preallocate
+        self.registery = KernelRegistry(M=M, d=d, nbits=nbits, nh=nh, scalar_t=scalar_t, device=device)
+        self.init_cache()
+
+    def init_cache(self):
+        nk, cap = self.num_key_value_heads, self.extended_residual_size
+        total = self.layer_num * self.bs * nk * self.n_pages_cap
+        z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=self.device)
+        self.key_page_pool = z(total, self.page_size, self.M, dt=torch.uint8)
+        self.value_page_pool = z(total, self.M, self.page_size, dt=torch.uint8)
+        self.page_manager = PageManager(self.page_size, initial_pages=total, max_pages=total, M=self.M)
+        self.page_ids = [z(self.bs, nk, self.n_pages_cap, dt=torch.int32) for _ in range(self.layer_num)]
+        self._pages_assigned = [0] * self.layer_num
+        self.key_residual_cache = [z(self.bs, nk, cap, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
+        self.value_residual_cache = [z(self.bs, nk, cap, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
+        self.lengths = [z(self.bs, 4, dt=torch.int32) for _ in range(self.layer_num)]     # device mirror
+        self.seen_tokens = [0] * self.layer_num
+        self.residualed_tokens = [0] * self.layer_num
+        self._T = [0] * self.layer_num
+        self._rstart = [0] * self.layer_num
+        self._ws = None
+        if self.preallocate:
+            for l in range(self.layer_num):
+                self._assign_pages(l, self.n_pages_cap)
+
+    def _assign_pages(self, layer_idx, upto_pages):
+        have = self._pages_assigned[layer_idx]
+        if upto_pages <= have:
+            return
+        if upto_pages > self.n_pages_cap:
+            raise RuntimeError(f"PagedPQCache: {upto_pages} pages exceed capacity {self.n_pages_cap} (max_tokens)")
+        n_new = upto_pages - have
+        ids = self.page_manager.allocate_pages(n_new * self.bs * self.num_key_value_heads)
+        t = torch.tensor(ids, dtype=torch.int32).reshape(self.bs, self.num_key_value_heads, n_new)
+        self.page_ids[layer_idx][:, :, have:upto_pages] = t.to(self.device)
+        self._pages_assigned[layer_idx] = upto_pages
+
+    def _sync_lengths(self, layer_idx):
+        self.lengths[layer_idx][:, 0] = self._T[layer_idx]
+        self.lengths[layer_idx][:, 1] = self.residualed_tokens[layer_idx]
+        self.lengths[layer_idx][:, 2] = self._rstart[layer_idx]
+
+    def _encode_to_pages(self, K, V, layer_idx, n, *, from_ring=False, use_dev_lengths=False):
+        T = self._T[layer_idx]
+        if not self.preallocate:
+            self._assign_pages(layer_idx, (T + n + self.page_size - 1) // self.page_size)
+        elif T + n > self.max_tokens:
+            raise RuntimeError(f"PagedPQCache: {T + n} tokens exceed max_tokens={self.max_tokens}")
+        kw = dict(token_start=T, n=n, page_ids=self.page_ids[layer_idx], page_size=self.page_size)
+        if from_ring:
+            kw.update(x_row_start=self._rstart[layer_idx], x_row_mod=self.extended_residual_size)
+        if use_dev_lengths:
+            kw.update(dev_lengths=self.lengths[layer_idx])
+        ops.pq_encode_into(K, self.key_cent, self.key_page_pool, layout=L.MILLION_CODES_KPAGES, **kw)
+        ops.pq_encode_into(V, self.value_cent, self.value_page_pool, layout=L.MILLION_CODES_VPAGES, **kw)
+
+    def prefill(self, query_states, key_states, value_states, layer_idx, distort_recent=False):
+        """Bulk encode of the prompt straight into pages (reference paged_pq_utils.py:216-320: encode,
+        torch.cat, per-page permute+contiguous); the residual window stays empty."""
+        n = key_states.size(2)
+        self._encode_to_pages(key_states, value_states, layer_idx, n)
+        self._T[layer_idx] += n
+        self.seen_tokens[layer_idx] += n
+        self._sync_lengths(layer_idx)
+        return self._prefill_attention(query_states, key_states, value_states)
+
+    def flush_to_pages(self, layer_idx: int, use_dev_lengths=False):
+        """Encode the oldest page_size residual rows into a new K page and V page (paged_pq_utils.py:130-210)."""
+        if self.residualed_tokens[layer_idx] < self.page_size:
+            return
+        self._encode_to_pages(self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], layer_idx,
+                              self.page_size, from_ring=True, use_dev_lengths=use_dev_lengths)
+        if use_dev_lengths:
+            ops.lengths_advance(self.lengths[layer_idx], self.page_size, self.extended_residual_size)
+        self._T[layer_idx] += self.page_size
+        self.residualed_tokens[layer_idx] -= self.page_size
+        self._rstart[layer_idx] = (self._rstart[layer_idx] + self.page_size) % self.extended_residual_size
+
+    def decoding_with_pages(self, query_states, key_states, value_states, layer_idx, out=None, use_dev_lengths=False):
+        """One decode step of one layer (paged_pq_utils.py:341-386): flush if the window is full, append the
+        new token's K/V row, fused attention over pages + window.  With use_dev_lengths=True every length
+        is read on the device (the host mirror is still advanced), which makes the call graph-capturable."""
+        if self.residualed_tokens[layer_idx] >= self.extended_residual_size:           # :359-361
+            self.flush_to_pages(layer_idx, use_dev_lengths=use_dev_lengths)
+        r, rs = self.residualed_tokens[layer_idx], self._rstart[layer_idx]
+        dl = self.lengths[layer_idx] if use_dev_lengths else None
+        if self._ws is None:      # one workspace per cache (calls of one cache are stream-ordered)
+            desc = ops.make_attn_desc(query_states, self.key_residual_cache[layer_idx], nh_k=self.num_key_value_heads,
+                                      M=self.M, C=self.C, n_tokens=0, r=0)
+            self._ws = torch.zeros(L.load().million_attn_workspace_bytes(desc), dtype=torch.uint8, device=self.device)
+        ops.residual_append(key_states, value_states, self.key_residual_cache[layer_idx],
+                            self.value_residual_cache[layer_idx], r, rs, dev_lengths=dl)   # :377-380
+        self.residualed_tokens[layer_idx] = r + 1
+        self.seen_tokens[layer_idx] += 1
+        return ops.pq_decode_attn(query_states, self.key_page_pool, self.value_page_pool, self._kprep, self._vprep,
+                                  self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], r + 1,
+                                  M=self.M, C=self.C, n_tokens=self.max_tokens if use_dev_lengths else self._T[layer_idx],
+                                  resid_start=rs, k_page_ids=self.page_ids[layer_idx],
+                                  v_page_ids=self.page_ids[layer_idx], page_size=self.page_size, out=out,
+                                  dev_lengths=dl, workspace=self._ws)
+
+    # the reference's non-paged entry point keeps working on the paged store
+    decoding = decoding_with_pages
+
+    # ---- host mirror management for captured (hipGraph) decode steps ------------------------------
+    # During stream capture the Python above runs once (advancing the host mirror) but no kernel
+    # executes; under replay the kernels run but no Python does.  The harness therefore restores the
+    # mirror after capture and calls note_replayed_step() after every replay.
+    def host_state(self):
+        return (list(self.seen_tokens), list(self.residualed_tokens), list(self._T), list(self._rstart))
+
+    def set_host_state(self, st):
+        self.seen_tokens, self.residualed_tokens, self._T, self._rstart = (list(x) for x in st)
+
+    def next_step_flushes(self, layer_idx: int = 0) -> bool:
+        return self.residualed_tokens[layer_idx] >= self.extended_residual_size
+
+    def note_replayed_step(self):
+        for l in range(self.layer_num):
+            if self.residualed_tokens[l] >= self.extended_residual_size:
+                self._T[l] += self.page_size
+                self.residualed_tokens[l] -= self.page_size
+                self._rstart[l] = (self._rstart[l] + self.page_size) % self.extended_residual_size
+            self.residualed_tokens[l] += 1
+            self.seen_tokens[l] += 1
+
+    def get_cache_stats(self) -> Dict:
+        """paged_pq_utils.py:898-939 (same keys) + the page-manager counters."""
+        layer_stats = [{"layer_idx": l, "seen_tokens": self.seen_tokens[l], "residual_tokens": self.residualed_tokens[l],
+                        "key_cache_tokens": self._T[l], "value_cache_tokens": self._T[l]} for l in range(self.layer_num)]
+        mb = 1024 * 1024
+        cache_mb = sum(2 * self.bs * self.num_key_value_heads * t * self.M for t in self._T) / mb
+        resid_mb = sum(c.numel() * c.element_size() for c in self.key_residual_cache + self.value_residual_cache) / mb
+        return {"layer_stats": layer_stats, "total_memory_usage_mb": cache_mb + resid_mb,
+                "memory_breakdown": {"cache_memory_mb": cache_mb, "residual_memory_mb": resid_mb,
+                                     "prefill_residual_memory_mb": 0.0, "total_memory_mb": cache_mb + resid_mb},
+                "page_manager": self.page_manager.get_stats()}

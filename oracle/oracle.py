@@ -356,3 +356,30 @@ class PagedPolicy:
             self.flushes += 1
         self.r += 1
         return self.T, self.r
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline (bench.py cpu_baseline leg): the reference's CPU-runnable PyTorch path, restated
+# --------------------------------------------------------------------------------------------------
+def decode_attn_torch_cpu(q, k_codes, v_codes, k_cents, v_cents, k_res, v_res, r: int, dtype="float32"):
+    """torch-CPU restatement of the reference's fallback math with the causal bug removed:
+    sa_decode_4d(K), sa_decode_4d(V) (pq_utils.py:501-540: expand + torch.gather) -> cat residual[:r]
+    -> repeat_kv -> scaled_dot_product_attention (paged_pq_utils.py:860-888, is_causal dropped).
+    Inputs are torch CPU tensors; runs on torch's intra-op thread pool."""
+    import torch
+
+    def sa_decode(codes, C):
+        bs, nh, n, M = codes.shape
+        _, c, dm = C.shape
+        Ce = C.unsqueeze(0).unsqueeze(0).expand(bs, nh, -1, -1, -1)
+        idx = codes.to(torch.long).unsqueeze(-1).expand(-1, -1, -1, -1, dm).unsqueeze(-2)
+        dec = torch.gather(Ce.unsqueeze(2).expand(-1, -1, n, -1, -1, -1), 4, idx).squeeze(4)
+        return dec.reshape(bs, nh, n, M * dm)
+
+    dt = getattr(torch, dtype)
+    q, k_cents, v_cents = q.to(dt), k_cents.to(dt), v_cents.to(dt)
+    K = torch.cat([sa_decode(k_codes, k_cents), k_res.to(dt)[:, :, :r]], dim=2)
+    V = torch.cat([sa_decode(v_codes, v_cents), v_res.to(dt)[:, :, :r]], dim=2)
+    G = q.shape[1] // K.shape[1]
+    K, V = K.repeat_interleave(G, dim=1), V.repeat_interleave(G, dim=1)
+    return torch.nn.functional.scaled_dot_product_attention(q, K, V)
