@@ -169,6 +169,10 @@ int million_residual_append(const void *k_new, const void *v_new, void *k_resid,
  * lengths: n_tokens += n_flushed, r -= n_flushed, resid_start = (resid_start + n_flushed) % resid_cap. */
 int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int resid_cap, million_stream_t stream);
 
+/* Diagnostics only: when `buf` is non-NULL the decode-attention kernels store up to 16 x uint64 realtime-counter
+ * stamps (100 MHz) per workgroup at their phase boundaries into buf (grid_size * 16 entries).  NULL = off. */
+void million_debug_set_stamp_buffer(void *buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,14 +17,14 @@ constexpr int kGenChunk = 2048;   // tokens scored per pass (S buffer in LDS)
 
 __device__ __forceinline__ const uint8_t *k_row_ptr(const AttnParams &p, int b, int hk, int bh, int t) {
     if (p.k_paged) {
-        const long long pid = page_id_at(p, p.k_page_ids, bh, t / p.page_size);
+        const long long pid = k_page_id(p, bh, t / p.page_size);
         return p.k_codes + (pid * p.page_size + (t % p.page_size)) * p.M;
     }
     return p.k_codes + b * p.k_sb + hk * p.k_sh + (long long)t * p.M;
 }
 __device__ __forceinline__ uint8_t v_code_at(const AttnParams &p, int b, int hk, int bh, int t, int m) {
     if (p.v_paged) {
-        const long long pid = page_id_at(p, p.v_page_ids, bh, t / p.page_size);
+        const long long pid = v_page_id(p, bh, t / p.page_size);
         return p.v_codes[(pid * p.M + m) * p.page_size + (t % p.page_size)];
     }
     return p.v_codes[b * p.v_sb + hk * p.v_sh + (long long)t * p.M + m];
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kGenBlock) void attn_generic_kernel(AttnParams p) {
         }
         __syncthreads();
     }
-    publish_and_merge(p, b, hk, slot, part, flag);
+    __syncthreads();
+    publish_and_merge(p, b, hk, slot, part, lut, flag);   // the LUT region is dead: merge scratch
 }
 
 int launch_attn_generic(const AttnParams &p, hipStream_t s) {

@@ -1,6 +1,693 @@
-// attn_mfma.hip — placeholder until the MFMA kernel lands (next commit).
+// attn_mfma.hip — fused decode attention over PQ code pages for the headline shapes
+// (d = 128, M = 64, C = 256, transposed V pages), hand-written for gfx950 / CDNA4.
+//
+// Replaces (one launch): the LUT matmul + flash_decoding_split_kernel + flash_decoding_residual_kernel
+// + torch::zeros + flash_decoding_reduce_kernel of the reference (Interface.template.cu:26-120,
+// Kernel.cuh:11-166, 1038-1270), and the intended paged-V kernel (MILLION_技术分析文档.md:1292-1345).
+//
+// Design (DESIGN.md "decode attention kernel"):
+//   * one 512-thread workgroup per CU; both codebooks live in LDS for the whole kernel:
+//       K table, row image [m][c] (4-byte entries): bank = code  -> random gather
+//       V table, col image [c][m] (4-byte entries): bank = m     -> conflict-free gather (lane = m)
+//   * all G = nh/nh_k query heads of a kv head are served by the same workgroup, so every code byte is
+//     read from HBM once per kv head (the reference re-reads it G times);
+//   * a wave walks 32-token units.  K side: lane = (token, 16-byte quarter of the code row); each code
+//     byte fetches its 2-dim centroid from LDS straight into the A operand of
+//     v_mfma_f32_16x16x32_f16 (rows = 16 tokens, K = 32 dims), B = the query heads -> fp32 scores with
+//     exact fp16 centroids (no fp16 LUT rounding).  V side: lane = subspace m; 16 consecutive token
+//     bytes of a transposed page row are one 16-byte load; looked-up centroids are packed into the B
+//     operand of v_mfma_f32_32x32x16_f16 (K = 16 tokens, cols = 32 subspaces), A = the probabilities of
+//     the G heads, moved from the score layout with v_permlane32_swap / v_permlane16_swap;
+//   * online softmax per wave in the exp2 domain, fp32; wave partials are merged through LDS, split
+//     partials through the workspace by the last-arriving workgroup (common.h:publish_and_merge);
+//   * the residual window (r <= 128 fp16 rows) is dealt round-robin to the splits and goes through the
+//     same MFMA score path (A = the fp16 K rows themselves); its V rows are accumulated with fp32 FMAs.
+//     Its rows are requested first thing in the kernel and consumed while the code ring is in flight.
 #include "common.h"
+
 namespace million {
-bool attn_mfma_supported(const AttnParams &) { return false; }
-int launch_attn_mfma(const AttnParams &, hipStream_t) { set_error("mfma kernel not built"); return MILLION_ERR_SHAPE; }
+
+typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int kNW = 8;                       // waves per workgroup
+static_assert(true, "");
+constexpr int kRing = 4;                     // 32-token units in flight per wave (16 VGPRs each)
+constexpr int kTabBytes = 64 * 1024;         // one codebook image (M*C*dm*2)
+constexpr int kVBase = kTabBytes;            // V col image behind the K row image
+constexpr int kPartOff = 2 * kTabBytes;      // [128K,136K): final partial, flag, residual (m, l)
+constexpr int kResWaves = 2;                 // residual groups (16 rows each) staged in LDS per workgroup
+constexpr int kResOut = kPartOff + 8192;     // [136K,144K): per group O_res[G][128] fp32
+constexpr int kResML = kPartOff + 6144;      // per group m[8], l[8]
+constexpr int kLdsBytes = kResOut + kResWaves * 4096;  // 144 KiB
+
+struct UnitCodes {
+    v4u k[2];   // K code bytes: group g2 (16 tokens), lane (q, c): token c, bytes [16q, 16q+16)
+    v4u v[2];   // V code bytes: half n (32 subspaces), lane (h, c): m = 32n + c, tokens [16h, 16h+16)
+};
+
+// LDS by absolute byte address: the dynamic LDS segment of this kernel starts at 0 (no static LDS; the
+// kernel traps otherwise), so a lookup address needs no base add.
+__device__ __forceinline__ unsigned lds32(unsigned addr) {
+    return *(const __attribute__((address_space(3))) unsigned *)(size_t)addr;
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ v8f16 as_v8f16(unsigned a, unsigned b, unsigned c, unsigned d) {
+    v4u t = {a, b, c, d};
+    return __builtin_bit_cast(v8f16, t);
+}
+
+// ---- how the vector-memory queue is kept deep without fighting hipcc's waitcnt insertion ------------
+// Every code / codebook / q load is a plain load the compiler can count, and NONE of them sits in a
+// conditional: slots past a wave's last unit re-request the unit holding token T-1 (L2 hits).  The
+// pending-load pattern at the loop header is then identical on entry and on the back edge, and hipcc
+// emits counted waits (vmcnt(12) before a unit: the three younger units stay in flight).  Versions with
+// conditional refills, or with LDS-DMA for the tables, made hipcc wait vmcnt(0) and drained the ring.
+//
+// Page ids come through the scalar cache in ONE asm statement (issue + wait): hipcc does not pick s_load
+// for them by itself, and a vector load of an id would sit in the vmcnt queue in front of the codes.
+struct PidPair { long long k, v; int k32, v32; };
+
+__device__ __forceinline__ PidPair load_pids(const AttnParams &p, int bh, int page) {
+    const unsigned idx = (unsigned)(bh * p.n_pages_cap + page);      // wave-uniform
+    PidPair o;
+    o.k = 0; o.k32 = 0; o.v32 = 0;
+    if (p.ids64) {
+        if (p.k_paged)
+            asm volatile("s_load_dwordx2 %0, %2, %4\n\ts_load_dwordx2 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(o.k), "=&s"(o.v) : "s"(p.k_ids64), "s"(p.v_ids64), "s"(idx * 8u) : "memory");
+        else
+            asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(o.v) : "s"(p.v_ids64), "s"(idx * 8u) : "memory");
+    } else {
+        int k32 = 0, v32;
+        if (p.k_paged)
+            asm volatile("s_load_dword %0, %2, %4\n\ts_load_dword %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(k32), "=&s"(v32) : "s"(p.k_ids32), "s"(p.v_ids32), "s"(idx * 4u) : "memory");
+        else
+            asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(v32) : "s"(p.v_ids32), "s"(idx * 4u) : "memory");
+        o.k = k32;
+        o.v = v32;
+    }
+    return o;
+}
+
+// The page ids of the ring's kRing first units: ONE scalar round trip, issued early (issue_pids4) and
+// waited for just before the code loads need them (wait_pids4).  Between the two statements the values
+// are in flight: nothing may read them (checked in the ISA: no s_mov of these SGPRs in between).
+__device__ __forceinline__ void issue_pids4(const AttnParams &p, int bh, const int (&page)[kRing], PidPair (&o)[kRing]) {
+    unsigned off[kRing];
+#pragma unroll
+    for (int k = 0; k < kRing; ++k) off[k] = (unsigned)(bh * p.n_pages_cap + page[k]) * (p.ids64 ? 8u : 4u);
+#pragma unroll
+    for (int k = 0; k < kRing; ++k) { o[k].k = 0; o[k].v = 0; o[k].k32 = 0; o[k].v32 = 0; }
+    if (p.ids64) {
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) {
+            asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(o[k].v) : "s"(p.v_ids64), "s"(off[k]));
+            if (p.k_paged) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(o[k].k) : "s"(p.k_ids64), "s"(off[k]));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) {
+            asm volatile("s_load_dword %0, %1, %2" : "=s"(o[k].v32) : "s"(p.v_ids32), "s"(off[k]));
+            if (p.k_paged) asm volatile("s_load_dword %0, %1, %2" : "=s"(o[k].k32) : "s"(p.k_ids32), "s"(off[k]));
+        }
+    }
+}
+__device__ __forceinline__ void wait_pids4(const AttnParams &p, PidPair (&o)[kRing]) {
+    if (p.ids64) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(o[0].k), "+s"(o[0].v), "+s"(o[1].k), "+s"(o[1].v), "+s"(o[2].k), "+s"(o[2].v), "+s"(o[3].k), "+s"(o[3].v)
+                     :: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(o[0].k32), "+s"(o[0].v32), "+s"(o[1].k32), "+s"(o[1].v32), "+s"(o[2].k32), "+s"(o[2].v32),
+                       "+s"(o[3].k32), "+s"(o[3].v32)
+                     :: "memory");
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) { o[k].k = o[k].k32; o[k].v = o[k].v32; }
+    }
+}
+
+// Request the 4 x 16-byte loads of one 32-token unit (see UnitCodes).  t_unit: multiple of 32, < T.
+__device__ __forceinline__ void load_unit_pid(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
+                                              int lane, UnitCodes &u) {
+    const int q4 = lane >> 4, c16 = lane & 15, h2i = lane >> 5, c32 = lane & 31;
+    const int page = t_unit >> p.ps_shift;                           // a unit never straddles a page
+    const int page0 = page << p.ps_shift;
+    const int inpage = t_unit - page0;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        int tok = t_unit + 16 * g2 + c16;
+        tok = tok < T ? tok : T - 1;                 // stay inside the store; masked later
+        const uint8_t *src = p.k_paged
+            ? p.k_codes + (((pid.k << p.ps_shift) + (tok - page0)) << 6) + 16 * q4
+            : p.k_codes + b * p.k_sb + hk * p.k_sh + ((long long)tok << 6) + 16 * q4;
+        u.k[g2] = *(const v4u *)src;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const uint8_t *src = p.v_codes + (((pid.v << 6) + 32 * n + c32) << p.ps_shift) + inpage + 16 * h2i;
+        u.v[n] = *(const v4u *)src;
+    }
+}
+__device__ __forceinline__ void load_unit(const AttnParams &p, int b, int hk, int bh, int t_unit, int T,
+                                          int lane, UnitCodes &u) {
+    load_unit_pid(p, b, hk, load_pids(p, bh, t_unit >> p.ps_shift), t_unit, T, lane, u);
+}
+
+// Online-softmax update shared by code units and residual groups.  sc[NS]: scaled scores (exp2 domain)
+// of this lane's tokens (-inf where masked).  Returns probabilities in sc.  Lanes with the same
+// (lane & 15) hold the same query head; the max is reduced over the four 16-lane rows.
+template <int NS>
+__device__ __forceinline__ void softmax_update(float (&sc)[NS], float &m_run, float &l_run, v16f32 (&O)[2][2],
+                                               int G, int lane) {
+    float mx = sc[0];
+#pragma unroll
+    for (int i = 1; i < NS; ++i) mx = fmaxf(mx, sc[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    // m_new is finite unless every token so far was masked; exp2(-inf - finite) = 0
+    const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+    const float alpha = fast_exp2(m_run - m_safe);
+    if (__any(m_new > m_run && m_run > -INFINITY)) {
+        // some head's running max moved: rescale the accumulators (rows of O are heads)
+        // alpha of head g sits in lane g; O rows: lanes < 32 hold heads rho, lanes >= 32 heads 4 + rho
+        const int hi4 = (lane >> 5) << 2;
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const float f = (hi4 + rho < G) ? __shfl(alpha, hi4 + rho, 64) : 1.0f;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
+        }
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const float pe = fast_exp2(sc[i] - m_safe);
+        sc[i] = pe;
+        ls += pe;
+    }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+}
+
+// One 32-token unit: scores (MFMA 16x16x32), online softmax, probabilities -> value MFMA (32x32x16).
+template <bool MASK>
+__device__ __forceinline__ void compute_unit(const UnitCodes &cur, const v8f16 (&qb)[4],
+                                             int t_unit, int t_end, float scale_log2e, int G, int lane,
+                                             unsigned kbase, unsigned vconst0, unsigned vconst1,
+                                             float &m_run, float &l_run, v16f32 (&O)[2][2]) {
+    const int q4 = lane >> 4;
+    // ---- scores: D[g2][rho] = S[token 16*g2 + 4*q' + rho][head lane&15] ----
+    v4f32 D[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        D[g2] = v4f32{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned w = cur.k[g2][s];
+            const unsigned a0 = lds32(kbase + (4 * s + 0) * 1024 + ((w & 0xffu) << 2));
+            const unsigned a1 = lds32(kbase + (4 * s + 1) * 1024 + (((w >> 8) & 0xffu) << 2));
+            const unsigned a2 = lds32(kbase + (4 * s + 2) * 1024 + (((w >> 16) & 0xffu) << 2));
+            const unsigned a3 = lds32(kbase + (4 * s + 3) * 1024 + ((w >> 24) << 2));
+            D[g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(a0, a1, a2, a3), qb[s], D[g2], 0, 0, 0);
+        }
+    }
+    float sc[8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const float v = D[g2][rho] * scale_log2e;
+            if (MASK) {
+                const int tok = t_unit + 16 * g2 + 4 * q4 + rho;
+                sc[g2 * 4 + rho] = tok < t_end ? v : -INFINITY;
+            } else {
+                sc[g2 * 4 + rho] = v;
+            }
+        }
+    softmax_update<8>(sc, m_run, l_run, O, G, lane);
+
+    // ---- probabilities -> A operand of the value MFMA (rows = heads, K = 16 tokens per step) ----
+    // pk[g2][i]: tokens 16*g2 + 4*q' + {2i, 2i+1} as packed fp16
+    unsigned pk[2][2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            h2 t = {(f16)sc[g2 * 4 + 2 * i], (f16)sc[g2 * 4 + 2 * i + 1]};
+            pk[g2][i] = __builtin_bit_cast(unsigned, t);
+        }
+    // step s uses tokens 16h + 8s + j: rows q' = 2s (j<4) and 2s+1 (j>=4) of group h
+    unsigned P[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const v2u x = __builtin_amdgcn_permlane32_swap(pk[0][i], pk[1][i], false, false);
+        // x[0] = {grp0 rows 0,1 | grp1 rows 0,1}  (step 0)   x[1] = {grp0 rows 2,3 | grp1 rows 2,3}  (step 1)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const v2u y = __builtin_amdgcn_permlane16_swap(x[s], x[s], false, false);
+            // y[0] rows {0,0,2,2} of x[s] ; y[1] rows {1,1,3,3} of x[s]
+            P[s][i] = y[0];
+            P[s][2 + i] = y[1];
+        }
+    }
+
+    // ---- values: O[n][kk] (rows = heads, cols = subspaces 32n..32n+31) += P (heads x 16 tokens) * Vhat ----
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const unsigned vconst = n ? vconst1 : vconst0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned w0 = cur.v[n][2 * s], w1 = cur.v[n][2 * s + 1];
+            const unsigned e0 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020400u));
+            const unsigned e1 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020500u));
+            const unsigned e2 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020600u));
+            const unsigned e3 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020700u));
+            const unsigned e4 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020400u));
+            const unsigned e5 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020500u));
+            const unsigned e6 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020600u));
+            const unsigned e7 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020700u));
+            const v8f16 B0 = as_v8f16(__builtin_amdgcn_perm(e1, e0, 0x05040100u), __builtin_amdgcn_perm(e3, e2, 0x05040100u),
+                                      __builtin_amdgcn_perm(e5, e4, 0x05040100u), __builtin_amdgcn_perm(e7, e6, 0x05040100u));
+            const v8f16 B1 = as_v8f16(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u),
+                                      __builtin_amdgcn_perm(e5, e4, 0x07060302u), __builtin_amdgcn_perm(e7, e6, 0x07060302u));
+            const v8f16 A = as_v8f16(P[s][0], P[s][1], P[s][2], P[s][3]);
+            O[n][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B0, O[n][0], 0, 0, 0);
+            O[n][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B1, O[n][1], 0, 0, 0);
+        }
+    }
+}
+
+// One group of <= 16 residual-window rows as an independent softmax partial (m, l, O_res): kraw = this
+// lane's K row slice (A operand of the score MFMA, lane (q4, row c16): dims 32*q4 + 8*s ..), vrow[i] = dims
+// (2*lane, 2*lane+1) of the i-th row's V.  nvalid = rows of the group that exist.  On return lane g < G
+// holds (m, l) of head g, ores[g] = sum_i p[g][i] * V[i][2*lane .. 2*lane+1].
+__device__ __forceinline__ void resid_group(const v4u (&kraw)[4], const h2 (&vrow)[16], int nvalid,
+                                            const v8f16 (&qb)[4], float scale_log2e, int G, int lane,
+                                            float &m_out, float &l_out, float (&ores)[kMaxG][2]) {
+    const int q4 = lane >> 4;
+    v4f32 D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        D = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, kraw[s]), qb[s], D, 0, 0, 0);
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+        sc[rho] = (4 * q4 + rho) < nvalid ? D[rho] * scale_log2e : -INFINITY;
+        mx = fmaxf(mx, sc[rho]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_safe = mx > -INFINITY ? mx : 0.f;
+    float ls = 0.f;
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+        sc[rho] = fast_exp2(sc[rho] - m_safe);
+        ls += sc[rho];
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    m_out = mx;
+    l_out = ls;
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) ores[g][0] = ores[g][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v0 = (float)vrow[i][0], v1 = (float)vrow[i][1];
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g)
+            if (g < G) {
+                // p of (row i, head g) sits in lane 16*(i/4) + g, register i%4: v_readlane -> SGPR operand
+                const float pg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                    __builtin_bit_cast(int, sc[i & 3]), (i >> 2) * 16 + g));
+                ores[g][0] = fmaf(pg, v0, ores[g][0]);
+                ores[g][1] = fmaf(pg, v1, ores[g][1]);
+            }
+    }
+}
+
+template <bool HAS_CODES>
+__global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int bh = blockIdx.y;
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int G = p.G;
+    // ---- lengths: device-resident (graph replay) -> one scalar load, issued now and waited for after the
+    //      codebook and q loads (which need no length) have been issued ----
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i dl = {p.T, p.r, p.rstart, 0};
+    if (p.dev_lengths) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u));
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    MILLION_STAMP(p, 0);
+    const int q4 = lane >> 4, c16 = lane & 15;
+
+    // B operand of the score MFMA: the query heads (cols), K = 32 dims per step.  Oldest loads of the
+    // wave: the residual partial below needs them before the codebooks are here.
+    v8f16 qb[4];
+    {
+        const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            v4u t = *(const v4u *)(qv + 8 * s);
+            if (c16 >= G) t = v4u{0, 0, 0, 0};
+            qb[s] = __builtin_bit_cast(v8f16, t);
+        }
+    }
+    // ---- both codebooks (16 x 16 B per thread): requested before anything that depends on a length ----
+    // Every workgroup needs the same 128 KiB at the same time: walking the 16 chunks in the same order
+    // would hammer one L2 channel after the other from all CUs, so each workgroup starts at its own chunk.
+    v4u tab[16];
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & 15;
+    {
+        const v4u *ks = (const v4u *)p.k_tab;
+        const v4u *vs = (const v4u *)p.v_tab_col;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = (i + rot) & 15;                       // wave-uniform
+            const v4u *src = ci < 8 ? ks + ci * (kNW * 64) : vs + (ci - 8) * (kNW * 64);
+            tab[i] = src[tid];
+        }
+    }
+    if (p.dev_lengths) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dl)::"memory");
+    int T = dl[0] < p.T ? dl[0] : p.T;     // the host value is the bound the grid was sized for
+    const int r = dl[1], rstart = dl[2];
+    if (T < 1) T = 0;
+    const int t_begin = min(split * p.split_len, T);
+    const int t_end = min(t_begin + p.split_len, T);
+    const int n_units = (t_end - t_begin + 31) >> 5;
+    const int n_mine = n_units > wave ? (n_units - wave + kNW - 1) / kNW : 0;   // units of this wave
+    const int n_pass = (n_mine + kRing - 1) / kRing;
+    // unit j of this wave starts at token t_begin + 32*(wave + j*kNW); slots past the last unit re-request
+    // the unit that holds token T-1 (HAS_CODES guarantees the host bound T >= 1; with device-resident
+    // lengths a runtime T of 0 reads page 0, which must be a valid page: million_hip.h)
+    const int T_ld = T > 0 ? T : 1;
+    const int t_last = (T_ld - 1) & ~31;
+#define UNIT_T(j) ((j) < n_mine ? t_begin + 32 * (wave + (j) * kNW) : t_last)
+    // page ids of the ring's first units: scalar loads issued here, waited for after the residual rows
+    // have been requested
+    int pg[kRing];
+    PidPair pid4[kRing];
+    if (HAS_CODES) {
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
+        issue_pids4(p, bh, pg, pid4);
+    }
+
+    // ---- residual window rows of this split: j = split, split + nsplit, ... < r; 16 rows per group.
+    //      Groups 0..kResWaves-1 (all of them unless a split holds > 32 window rows) are requested by waves
+    //      0..kResWaves-1 before everything else (OLDER loads never make a later counted wait over-wait),
+    //      parked in LDS next to the tables, and turned into their own softmax partial right after the
+    //      barrier, in the shadow of the code loads.  Later groups take the slow path at the end. ----
+    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
+    const int rgroups = (rcnt + 15) >> 4;
+    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    const bool res_wave = wave < kResWaves && wave < rgroups;      // wave-uniform
+    v4u rk[4];
+    h2 rv[16];
+    if (res_wave) {
+        const int i_lane = wave * 16 + c16;
+        const int j_lane = split + (i_lane < rcnt ? i_lane : 0) * p.nsplit;
+        int row_l = rstart + j_lane;
+        row_l = row_l >= p.rcap ? row_l - p.rcap : row_l;      // rstart, j < rcap: one wrap at most
+        const f16 *kp = kr + (long long)row_l * 128 + 32 * q4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rk[s] = *(const v4u *)(kp + 8 * s);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ii = wave * 16 + i;
+            const int j = split + (ii < rcnt ? ii : 0) * p.nsplit;        // wave-uniform
+            int row_i = rstart + j;
+            row_i = row_i >= p.rcap ? row_i - p.rcap : row_i;
+            rv[i] = *(const h2 *)(vr + (long long)row_i * 128 + 2 * lane);
+        }
+    }
+
+    UnitCodes ring[kRing];
+    if (HAS_CODES) {
+        wait_pids4(p, pid4);
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) load_unit_pid(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
+    }
+    MILLION_STAMP(p, 9);
+    // this wave's residual group -> its own softmax partial (m, l, O_res) in LDS.  Its rows are the oldest
+    // loads of the wave, so this runs while the codebooks and the codes are still on their way.
+    if (res_wave) {
+        // opaque use AFTER every load of the prologue has been issued: keeps hipcc from hoisting the
+        // fp16->fp32 conversions (and with them the wait for these rows) above the table / code loads
+        asm volatile("" : "+v"(rk[0]), "+v"(rk[1]), "+v"(rk[2]), "+v"(rk[3]), "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]),
+                          "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]), "+v"(rv[8]), "+v"(rv[9]),
+                          "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]), "+v"(rv[15]));
+        const int nv = rcnt - wave * 16;
+        float mr, lr, ores[kMaxG][2];
+        resid_group(rk, rv, nv < 16 ? nv : 16, qb, p.scale_log2e, G, lane, mr, lr, ores);
+        float *ro = (float *)(smem + kResOut + wave * 4096);
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g)
+            if (g < G) *(float2 *)(ro + g * 128 + 2 * lane) = float2{ores[g][0], ores[g][1]};
+        if (lane < G) {
+            float *ml = (float *)(smem + kResML) + wave * 16;
+            ml[lane] = mr;
+            ml[8 + lane] = lr;
+        }
+    }
+    MILLION_STAMP(p, 7);
+    {
+        v4u *ld = (v4u *)smem;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ld[((i + rot) & 15) * (kNW * 64) + tid] = tab[i];
+    }
+    MILLION_STAMP(p, 8);
+    __syncthreads();     // no LDS-DMA in flight: lgkmcnt(0) + s_barrier, the code ring stays in flight
+    MILLION_STAMP(p, 1);
+    float m_run = -INFINITY, l_run = 0.f;
+    v16f32 O[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
+    MILLION_STAMP(p, 2);
+
+
+    const unsigned kbase = (unsigned)q4 * 16u * 1024u;                 // K row image: m = 16*q4 + ...
+    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);        // m = c
+    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);  // m = 32 + c
+
+    if (HAS_CODES) {
+        // all passes but the last: every unit exists; consume a slot, then refill it unconditionally
+        for (int pass = 0; pass + 1 < n_pass; ++pass) {
+#pragma unroll
+            for (int k = 0; k < kRing; ++k) {
+                const int j = pass * kRing + k;
+                compute_unit<false>(ring[k], qb, t_begin + 32 * (wave + j * kNW), t_end, p.scale_log2e, G, lane, kbase,
+                                    vconst0, vconst1, m_run, l_run, O);
+                load_unit(p, b, hk, bh, UNIT_T(j + kRing), T_ld, lane, ring[k]);
+            }
+        }
+        // last pass: no refills, so the waits count down 12, 8, 4, 0
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) {
+            const int j = (n_pass - 1) * kRing + k;
+            if (n_pass > 0 && j < n_mine)     // the last unit of a split can be partial: masked variant
+                compute_unit<true>(ring[k], qb, t_begin + 32 * (wave + j * kNW), t_end, p.scale_log2e, G, lane, kbase,
+                                   vconst0, vconst1, m_run, l_run, O);
+        }
+    }
+#undef UNIT_T
+    // residual groups beyond the LDS-staged ones (only when a split holds more than 32 window rows):
+    // slow path, loads inside; each becomes a partial merged online into (m_late, l_late, olate)
+    float m_late = -INFINITY, l_late = 0.f, olate[kMaxG][2];
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) olate[g][0] = olate[g][1] = 0.f;
+    for (int gi = kResWaves + wave; gi < rgroups; gi += kNW) {
+        const int i_lane = gi * 16 + c16;
+        const int j_lane = split + (i_lane < rcnt ? i_lane : 0) * p.nsplit;
+        int row_l = rstart + j_lane;
+        row_l = row_l >= p.rcap ? row_l - p.rcap : row_l;      // rstart, j < rcap: one wrap at most
+        const f16 *kp = kr + (long long)row_l * 128 + 32 * q4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rk[s] = *(const v4u *)(kp + 8 * s);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ii = gi * 16 + i;
+            const int j = split + (ii < rcnt ? ii : 0) * p.nsplit;
+            int row_i = rstart + j;
+            row_i = row_i >= p.rcap ? row_i - p.rcap : row_i;
+            rv[i] = *(const h2 *)(vr + (long long)row_i * 128 + 2 * lane);
+        }
+        const int nv = rcnt - gi * 16;
+        float mr, lr, ores[kMaxG][2];
+        resid_group(rk, rv, nv < 16 ? nv : 16, qb, p.scale_log2e, G, lane, mr, lr, ores);
+        // (m, l) of head g live in lane g; the O_res rows live per lane -> broadcast the scale factors
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g)
+            if (g < G) {
+                const float mg = __shfl(mr, g, 64), ml = __shfl(m_late, g, 64);
+                const float mn = fmaxf(mg, ml), ms = mn > -INFINITY ? mn : 0.f;
+                const float fa = fast_exp2(ml - ms), fb = fast_exp2(mg - ms);
+                olate[g][0] = olate[g][0] * fa + ores[g][0] * fb;
+                olate[g][1] = olate[g][1] * fa + ores[g][1] * fb;
+            }
+        {
+            const float mn = fmaxf(mr, m_late), ms = mn > -INFINITY ? mn : 0.f;
+            l_late = l_late * fast_exp2(m_late - ms) + lr * fast_exp2(mr - ms);
+            m_late = mn;
+        }
+    }
+    MILLION_STAMP(p, 3);
+    // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    MILLION_STAMP(p, 4);
+    const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
+    float *scr = (float *)smem;
+    float *mine = scr + wave * wstride;
+    {
+        const bool hi = lane >= 32;
+        const int c32 = lane & 31;
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const int g = hi ? 4 + rho : rho;
+            if (g < G) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) mine[g * 128 + 2 * (32 * n + c32) + kk] = O[n][kk][rho];
+            }
+        }
+        if (lane < G) {                                  // lane g: row q' = 0, col g
+            mine[G * 128 + lane] = m_run;
+            mine[G * 128 + kMaxG + lane] = l_run;
+        }
+    }
+    // late residual partial of this wave: fold into the wave's entry (same wave: LDS ops are ordered)
+    if (kResWaves + wave < rgroups) {
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g)
+            if (g < G) {
+                const float mw_ = mine[G * 128 + g], ml = __shfl(m_late, g, 64), ll = __shfl(l_late, g, 64);
+                const float mn = fmaxf(mw_, ml), ms = mn > -INFINITY ? mn : 0.f;
+                const float fa = fast_exp2(mw_ - ms), fb = fast_exp2(ml - ms);
+                mine[g * 128 + 2 * lane] = mine[g * 128 + 2 * lane] * fa + olate[g][0] * fb;
+                mine[g * 128 + 2 * lane + 1] = mine[g * 128 + 2 * lane + 1] * fa + olate[g][1] * fb;
+                if (lane == 0) {
+                    mine[G * 128 + kMaxG + g] = mine[G * 128 + kMaxG + g] * fa + ll * fb;
+                    mine[G * 128 + g] = mn;
+                }
+            }
+    }
+    __syncthreads();
+    float *part = (float *)(smem + kPartOff);
+    int *flag = (int *)(part + G * 128 + 2 * G + 4);
+    for (int e = tid; e < G * 128; e += kNW * 64) {
+        const int g = e >> 7;
+        float mw[kNW], vw[kNW], lw[kNW];
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) {
+            mw[w] = scr[w * wstride + G * 128 + g];
+            vw[w] = scr[w * wstride + e];
+            lw[w] = scr[w * wstride + G * 128 + kMaxG + g];
+        }
+        // LDS-staged residual partials (groups 0..kResWaves-1)
+        float mr[kResWaves], vr_[kResWaves], lr[kResWaves];
+#pragma unroll
+        for (int w = 0; w < kResWaves; ++w) {
+            const bool on = w < rgroups;
+            const float *ml = (const float *)(smem + kResML) + w * 16;
+            mr[w] = on ? ml[g] : -INFINITY;
+            lr[w] = on ? ml[8 + g] : 0.f;
+            vr_[w] = on ? ((const float *)(smem + kResOut + w * 4096))[e] : 0.f;
+        }
+        float Mx = mw[0];
+#pragma unroll
+        for (int w = 1; w < kNW; ++w) Mx = fmaxf(Mx, mw[w]);
+#pragma unroll
+        for (int w = 0; w < kResWaves; ++w) Mx = fmaxf(Mx, mr[w]);
+        const float Ms = Mx > -INFINITY ? Mx : 0.f;
+        float acc = 0.f, lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) {
+            const float f = fast_exp2(mw[w] - Ms);      // -inf -> 0
+            acc = fmaf(f, vw[w], acc);
+            lsum = fmaf(f, lw[w], lsum);
+        }
+#pragma unroll
+        for (int w = 0; w < kResWaves; ++w) {
+            const float f = fast_exp2(mr[w] - Ms);
+            acc = fmaf(f, vr_[w], acc);
+            lsum = fmaf(f, lr[w], lsum);
+        }
+        part[e] = acc;
+        if ((e & 127) == 0) {
+            part[G * 128 + g] = Mx;
+            part[G * 128 + G + g] = lsum;
+        }
+    }
+    __syncthreads();
+    MILLION_STAMP(p, 5);
+    publish_and_merge(p, b, hk, split, part, scr, flag);
+    MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
+}
+
+bool attn_mfma_supported(const AttnParams &p) {
+    return p.d == 128 && p.M == 64 && p.C == 256 && p.v_paged && p.G <= kMaxG &&
+           (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
+}
+
+int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
+    AttnParams p = p_in;
+    // split policy: about one workgroup per CU; a split is a multiple of 64 tokens, at least 512 long
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int bh = p.bs * p.nh_k;
+    int ns = (cus + bh - 1) / bh;
+    if (ns > kMaxSplits) ns = kMaxSplits;
+    const int by_len = p.T > 0 ? (p.T + 511) / 512 : 1;
+    if (ns > by_len) ns = by_len;
+    if (ns < 1) ns = 1;
+    int len = p.T > 0 ? (p.T + ns - 1) / ns : 64;
+    len = (len + 63) / 64 * 64;
+    ns = p.T > 0 ? (p.T + len - 1) / len : 1;
+    p.nsplit = ns;
+    p.nslots = ns;
+    p.split_len = len;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = true;
+    }
+    if (p.T > 0)
+        hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+    else
+        hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("attn_mfma launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
+}  // namespace million

@@ -18,8 +18,11 @@ struct AttnParams {
     const f16 *q;
     const uint8_t *k_codes;
     const uint8_t *v_codes;
-    const void *k_page_ids;
-    const void *v_page_ids;
+    // page ids, typed + restrict (read-only in every kernel): uniform indices become scalar loads
+    const int *__restrict__ k_ids32;
+    const int *__restrict__ v_ids32;
+    const long long *__restrict__ k_ids64;
+    const long long *__restrict__ v_ids64;
     const f16 *k_tab;      // prepared K table, row image [m][c][dm]
     const f16 *k_tab_col;  // prepared K table, col image [c][m][dm]
     const f16 *v_tab;      // prepared V table, row image
@@ -29,16 +32,17 @@ struct AttnParams {
     f16 *out;
     float *ws_part;
     int *ws_cnt;
-    const int *dev_lengths;
+    const int *__restrict__ dev_lengths;
     int bs, nh, nh_k, G, d, M, C, dm;
     int T, r, rstart, rcap;
     long long res_sb, res_sh, k_sb, k_sh, v_sb, v_sh;
-    int k_paged, v_paged, page_size, n_pages_cap, ids64;
+    int k_paged, v_paged, page_size, ps_shift, n_pages_cap, ids64;
     int nsplit;      // code splits per (b, hk)
     int nslots;      // partial slots per (b, hk)
     int split_len;   // tokens per split
     int slot_floats; // floats per partial slot = G*d + 2*G (padded to 4)
     float scale_log2e;
+    unsigned long long *dbg;   // diagnostic stamp buffer (million_debug_set_stamp_buffer), normally null
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -63,10 +67,22 @@ __device__ __forceinline__ void load_lengths(const AttnParams &p, int b, int &T,
     }
 }
 
-__device__ __forceinline__ long long page_id_at(const AttnParams &p, const void *ids, int bh, int page) {
+__device__ __forceinline__ long long k_page_id(const AttnParams &p, int bh, int page) {
     const long long idx = (long long)bh * p.n_pages_cap + page;
-    return p.ids64 ? ((const long long *)ids)[idx] : (long long)((const int *)ids)[idx];
+    return p.ids64 ? p.k_ids64[idx] : (long long)p.k_ids32[idx];
 }
+__device__ __forceinline__ long long v_page_id(const AttnParams &p, int bh, int page) {
+    const long long idx = (long long)bh * p.n_pages_cap + page;
+    return p.ids64 ? p.v_ids64[idx] : (long long)p.v_ids32[idx];
+}
+
+// Diagnostic stamps (off unless a buffer is set): lane 0 of each workgroup stores the 100 MHz realtime
+// counter at phase boundaries; 16 slots per workgroup.  Never read by any kernel.
+#define MILLION_STAMP(p, i)                                                                              \
+    do {                                                                                                 \
+        if ((p).dbg && threadIdx.x == 0)                                                                 \
+            (p).dbg[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 // ---- inter-workgroup hand-off of split partials (cdna_hip_programming.md, Guideline 16, R1 counter form) ----
 // Producer: agent-scope relaxed (sc1, write-through) stores of the partial, every storing wave drains
@@ -81,9 +97,10 @@ __device__ __forceinline__ float ld_agent(const float *p) {
 }
 
 // part_lds: this workgroup's partial in LDS: O[G][d] (unnormalised, relative to m), then m[G] (log2
-// domain), then l[G].  flag_lds: one int of LDS scratch.  All threads of the workgroup call this.
+// domain), then l[G].  scratch: >= (2*nslots*G + 2*G) floats of LDS nobody else uses any more.
+// flag_lds: one int of LDS scratch.  All threads of the workgroup call this.
 __device__ __forceinline__ void publish_and_merge(const AttnParams &p, int b, int hk, int slot,
-                                                  const float *part_lds, int *flag_lds) {
+                                                  const float *part_lds, float *scratch, int *flag_lds) {
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int bh = b * p.nh_k + hk;
@@ -98,28 +115,71 @@ __device__ __forceinline__ void publish_and_merge(const AttnParams &p, int b, in
         *flag_lds = (t == p.nslots - 1);
     }
     __syncthreads();
+    MILLION_STAMP(p, 10);
     if (!*flag_lds) return;
 
-    // ---- last arriver: merge all slots of (b, hk) ----
-    const float *src = p.ws_part + (long long)bh * p.nslots * p.slot_floats;
-    for (int i = tid; i < G * d; i += nthr) {
-        const int g = i / d;
-        float mx = -INFINITY;
-        for (int s = 0; s < p.nslots; ++s) mx = fmaxf(mx, ld_agent(src + (long long)s * p.slot_floats + G * d + g));
-        float num = 0.f, den = 0.f;
-        if (mx > -INFINITY) {
-            for (int s = 0; s < p.nslots; ++s) {
-                const float *sp = src + (long long)s * p.slot_floats;
-                const float ms = ld_agent(sp + G * d + g);
-                if (ms > -INFINITY) {
-                    const float w = exp2f(ms - mx);
-                    num += w * ld_agent(sp + i);
-                    den += w * ld_agent(sp + G * d + G + g);
-                }
+    // ---- last arriver: merge all slots of (b, hk); every load of handed-off bytes is an sc1 load ----
+    // One memory round trip: each thread first requests the values of its output element from up to
+    // kMergeBatch slots; meanwhile wave w turns the (m, l) pairs of head g = w, w + nwaves, ... into
+    // softmax weights (lane = slot, wave max / sum) and leaves them in LDS; one barrier; every thread
+    // then combines its values with the weights of its head.
+    constexpr int kMergeBatch = 32;
+    const int ns = p.nslots;
+    const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
+    const bool fast = (G * d <= nthr) && (ns <= kMergeBatch);      // workgroup-uniform: straight-line path
+    float v[kMergeBatch];
+    if (fast) {
+        const int e0 = tid < G * d ? tid : 0;
+#pragma unroll
+        for (int k = 0; k < kMergeBatch; ++k) v[k] = ld_agent(src + (long long)(k < ns ? k : ns - 1) * p.slot_floats + e0);
+    }
+    {
+        const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+        for (int g = wv; g < G; g += nwv) {
+            const bool on = lane < ns;      // ns <= kMaxSplits + 1 = 65 > 64: slot 64 handled by lane 63 below
+            float m0 = on ? ld_agent(src + (long long)lane * p.slot_floats + G * d + g) : -INFINITY;
+            float l0 = on ? ld_agent(src + (long long)lane * p.slot_floats + G * d + G + g) : 0.f;
+            float m1 = -INFINITY, l1 = 0.f;
+            if (ns > 64 && lane == 63) {
+                m1 = ld_agent(src + 64ll * p.slot_floats + G * d + g);
+                l1 = ld_agent(src + 64ll * p.slot_floats + G * d + G + g);
             }
+            const float mx = wave_max(fmaxf(m0, m1));
+            const float ms_ = mx > -INFINITY ? mx : 0.f;
+            const float w0 = exp2f(m0 - ms_), w1 = exp2f(m1 - ms_);       // m = -inf -> 0
+            const float den = wave_sum(w0 * l0 + w1 * l1);
+            const float inv = den > 0.f ? 1.0f / den : 0.f;
+            if (on) scratch[lane * G + g] = w0 * inv;
+            if (ns > 64 && lane == 63) scratch[64 * G + g] = w1 * inv;
         }
-        const float o = den > 0.f ? num / den : 0.f;
-        p.out[((long long)b * p.nh + hk * G + g) * d + (i - g * d)] = (f16)o;
+    }
+    __syncthreads();
+    MILLION_STAMP(p, 11);
+    if (fast) {
+        if (tid < G * d) {
+            const int g = tid / d;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMergeBatch; ++k) {
+                const float w = k < ns ? scratch[k * G + g] : 0.f;
+                acc = fmaf(w, v[k], acc);
+            }
+            p.out[((long long)b * p.nh + hk * G + g) * d + (tid - g * d)] = (f16)acc;
+        }
+    } else {
+        for (int e = tid; e < G * d; e += nthr) {
+            const int g = e / d;
+            float acc = 0.f;
+            for (int s0 = 0; s0 < ns; s0 += kMergeBatch) {
+#pragma unroll
+                for (int k = 0; k < kMergeBatch; ++k)
+                    v[k] = ld_agent(src + (long long)(s0 + k < ns ? s0 + k : ns - 1) * p.slot_floats + e);
+#pragma unroll
+                for (int k = 0; k < kMergeBatch; ++k)
+                    if (s0 + k < ns) acc = fmaf(scratch[(s0 + k) * G + g], v[k], acc);
+            }
+            p.out[((long long)b * p.nh + hk * G + g) * d + (e - g * d)] = (f16)acc;
+        }
     }
     if (tid == 0) __hip_atomic_store(p.ws_cnt + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

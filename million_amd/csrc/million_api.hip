@@ -9,6 +9,7 @@ namespace million {
 
 static thread_local char g_err[512] = "";
 static int g_force_generic = 0;
+static unsigned long long *g_dbg = nullptr;
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -91,6 +92,7 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     if ((desc->k_layout != MILLION_KV_PAGED && desc->k_layout != MILLION_KV_ROWMAJOR) ||
         (desc->v_layout != MILLION_KV_PAGED && desc->v_layout != MILLION_KV_ROWMAJOR)) { set_error("attn: k_layout=%d v_layout=%d", desc->k_layout, desc->v_layout); return MILLION_ERR_ARG; }
     p.page_size = desc->page_size; p.n_pages_cap = desc->n_pages_cap; p.ids64 = desc->page_ids_i64;
+    p.ps_shift = p.page_size == 32 ? 5 : p.page_size == 64 ? 6 : 7;
     if (p.k_paged || p.v_paged) {
         if (p.page_size != 32 && p.page_size != 64 && p.page_size != 128) { set_error("attn: page_size=%d (32, 64, 128)", p.page_size); return MILLION_ERR_SHAPE; }
         if ((long long)p.n_pages_cap * p.page_size < p.T) { set_error("attn: n_pages_cap*page_size < n_tokens"); return MILLION_ERR_ARG; }
@@ -129,6 +131,7 @@ extern "C" {
 int million_version(void) { return MILLION_HIP_VERSION; }
 const char *million_last_error(void) { return g_err; }
 void million_set_force_generic(int on) { g_force_generic = on; }
+void million_debug_set_stamp_buffer(void *buf) { g_dbg = (unsigned long long *)buf; }
 
 size_t million_prepared_cents_bytes(int M, int C, int d_m) { return (size_t)2 * M * C * d_m * sizeof(f16); }
 
@@ -212,13 +215,15 @@ int million_pq_decode_attn(const million_attn_desc *desc, const void *q, const v
     if ((p.res_sb | p.res_sh) & 7) { set_error("attn: residual strides must be multiples of 8 elements"); return MILLION_ERR_ALIGN; }
     const size_t tab = (size_t)p.M * p.C * p.dm;
     p.q = (const f16 *)q; p.k_codes = (const uint8_t *)k_codes; p.v_codes = (const uint8_t *)v_codes;
-    p.k_page_ids = k_page_ids; p.v_page_ids = v_page_ids;
+    p.k_ids32 = (const int *)k_page_ids; p.k_ids64 = (const long long *)k_page_ids;
+    p.v_ids32 = (const int *)v_page_ids; p.v_ids64 = (const long long *)v_page_ids;
     p.k_tab = (const f16 *)k_cents_prepared; p.k_tab_col = p.k_tab + tab;
     p.v_tab = (const f16 *)v_cents_prepared; p.v_tab_col = p.v_tab + tab;
     p.k_res = (const f16 *)k_resid; p.v_res = (const f16 *)v_resid; p.out = (f16 *)out;
     size_t cnt = (size_t)p.bs * p.nh_k * sizeof(int);
     cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
     p.ws_cnt = (int *)workspace;
+    p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
     if (!g_force_generic && attn_mfma_supported(p)) return launch_attn_mfma(p, (hipStream_t)stream);
     choose_splits(p, 256);
