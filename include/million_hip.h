@@ -148,6 +148,18 @@ int million_pq_decode_attn(const million_attn_desc *desc,
                            void *workspace, size_t workspace_bytes,
                            million_stream_t stream);
 
+/* Same, fused with the residual-window append of the new token (replaces the two slice-assign copies of
+ * DynamicPQCache.decoding, scripts/utils/pq_utils.py:304-312, AND the attention launch that follows them,
+ * :314-326): k_new / v_new (bs, nh_k, 1, d) fp16 are attended to as one more window row and stored into
+ * row (resid_start + r) % resid_cap of k_resid / v_resid, where r = desc->r is the number of valid rows
+ * BEFORE the call (r < resid_cap).  With dev_lengths the row count is read on the device and incremented
+ * there once every workgroup has read it. */
+int million_pq_decode_attn_append(const million_attn_desc *desc, const void *q, const void *k_new, const void *v_new,
+                                  const void *k_codes, const void *v_codes, const void *k_page_ids,
+                                  const void *v_page_ids, const void *k_cents_prepared,
+                                  const void *v_cents_prepared, void *k_resid, void *v_resid, void *out,
+                                  void *workspace, size_t workspace_bytes, million_stream_t stream);
+
 /* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = MFMA fast path, 0 = generic. */
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Force the generic kernel (A/B measurements and tests): 0 = auto (default), 1 = generic only. */

@@ -46,6 +46,8 @@ SYMBOLS = {
     "million_workspace_init": (c_i32, [c_vp, c_sz, c_vp]),
     "million_pq_decode_attn": (c_i32, [ctypes.POINTER(AttnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "million_pq_decode_attn_append": (c_i32, [ctypes.POINTER(AttnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "million_attn_kernel_kind": (c_i32, [ctypes.POINTER(AttnDesc)]),
     "million_set_force_generic": (None, [c_i32]),
     "million_debug_set_stamp_buffer": (None, [c_vp]),

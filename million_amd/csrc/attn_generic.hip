@@ -50,6 +50,8 @@ __global__ __launch_bounds__(kGenBlock) void attn_generic_kernel(AttnParams p) {
     const int G = p.G, d = p.d, M = p.M, C = p.C, dm = p.dm;
     int T, r, rstart;
     load_lengths(p, b, T, r, rstart);
+    const int r_old = r;
+    if (p.k_new) r += 1;                      // fused append: the new token is window row r_old
 
     float *lut = (float *)smem;                          // [M*C]
     float *S = lut + M * C;                              // [kGenChunk]
@@ -66,6 +68,11 @@ __global__ __launch_bounds__(kGenBlock) void attn_generic_kernel(AttnParams p) {
     const int vdim = tid % d, vph = tid / d;
     const int vm = vdim / dm, vk = vdim % dm;
 
+    if (p.k_new && is_resid && tid < d) {           // fused append: park the new row in the window
+        const long long o = b * p.res_sb + hk * p.res_sh + (long long)((rstart + r_old) % p.rcap) * d + tid;
+        p.k_res_w[o] = p.k_new[(long long)bh * d + tid];
+        p.v_res_w[o] = p.v_new[(long long)bh * d + tid];
+    }
     for (int g = 0; g < G; ++g) {
         const int h = hk * G + g;
         const f16 *qv = p.q + ((long long)b * p.nh + h) * d;
@@ -103,7 +110,8 @@ __global__ __launch_bounds__(kGenBlock) void attn_generic_kernel(AttnParams p) {
                     s = a * p.scale_log2e;
                 } else {
                     const int row = (rstart + c0 + i) % p.rcap;
-                    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh + (long long)row * d;
+                    const f16 *kr = (p.k_new && c0 + i == r_old) ? p.k_new + (long long)bh * d
+                                                                 : p.k_res + b * p.res_sb + hk * p.res_sh + (long long)row * d;
                     float a = 0.f;
                     for (int k = 0; k < d; ++k) a = fmaf(qs[k], (float)kr[k], a);
                     s = a * p.scale_log2e;
@@ -134,7 +142,9 @@ __global__ __launch_bounds__(kGenBlock) void attn_generic_kernel(AttnParams p) {
                 } else {
                     for (int i = vph; i < cn; i += nph) {
                         const int row = (rstart + c0 + i) % p.rcap;
-                        acc = fmaf(S[i], (float)p.v_res[b * p.res_sb + hk * p.res_sh + (long long)row * d + vdim], acc);
+                        const f16 vv = (p.v_new && c0 + i == r_old) ? p.v_new[(long long)bh * d + vdim]
+                                                                    : p.v_res[b * p.res_sb + hk * p.res_sh + (long long)row * d + vdim];
+                        acc = fmaf(S[i], (float)vv, acc);
                     }
                 }
             }

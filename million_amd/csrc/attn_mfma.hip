@@ -386,7 +386,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     }
     if (p.dev_lengths) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dl)::"memory");
     int T = dl[0] < p.T ? dl[0] : p.T;     // the host value is the bound the grid was sized for
-    const int r = dl[1], rstart = dl[2];
+    const int r_old = dl[1], rstart = dl[2];
+    const int r = r_old + (p.k_new ? 1 : 0);       // fused append: the new token is window row r_old
     if (T < 1) T = 0;
     const int t_begin = min(split * p.split_len, T);
     const int t_end = min(t_begin + p.split_len, T);
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         const int j_lane = split + (i_lane < rcnt ? i_lane : 0) * p.nsplit;
         int row_l = rstart + j_lane;
         row_l = row_l >= p.rcap ? row_l - p.rcap : row_l;      // rstart, j < rcap: one wrap at most
-        const f16 *kp = kr + (long long)row_l * 128 + 32 * q4;
+        const f16 *kp = (p.k_new && j_lane == r_old ? p.k_new + (long long)bh * 128 : kr + (long long)row_l * 128) + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) rk[s] = *(const v4u *)(kp + 8 * s);
 #pragma unroll
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             const int j = split + (ii < rcnt ? ii : 0) * p.nsplit;        // wave-uniform
             int row_i = rstart + j;
             row_i = row_i >= p.rcap ? row_i - p.rcap : row_i;
-            rv[i] = *(const h2 *)(vr + (long long)row_i * 128 + 2 * lane);
+            rv[i] = *(const h2 *)((p.v_new && j == r_old ? p.v_new + (long long)bh * 128 : vr + (long long)row_i * 128) + 2 * lane);
         }
     }
 
@@ -444,6 +445,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         wait_pids4(p, pid4);
 #pragma unroll
         for (int k = 0; k < kRing; ++k) load_unit_pid(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
+    }
+    if (p.k_new && split == 0 && wave == kNW - 1) {      // fused append: park the new row in the window
+        int row_n = rstart + r_old;
+        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
+        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
+        *(h2 *)(p.k_res_w + o) = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
+        *(h2 *)(p.v_res_w + o) = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
     }
     MILLION_STAMP(p, 9);
     // this wave's residual group -> its own softmax partial (m, l, O_res) in LDS.  Its rows are the oldest
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         const int j_lane = split + (i_lane < rcnt ? i_lane : 0) * p.nsplit;
         int row_l = rstart + j_lane;
         row_l = row_l >= p.rcap ? row_l - p.rcap : row_l;      // rstart, j < rcap: one wrap at most
-        const f16 *kp = kr + (long long)row_l * 128 + 32 * q4;
+        const f16 *kp = (p.k_new && j_lane == r_old ? p.k_new + (long long)bh * 128 : kr + (long long)row_l * 128) + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) rk[s] = *(const v4u *)(kp + 8 * s);
 #pragma unroll
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             const int j = split + (ii < rcnt ? ii : 0) * p.nsplit;
             int row_i = rstart + j;
             row_i = row_i >= p.rcap ? row_i - p.rcap : row_i;
-            rv[i] = *(const h2 *)(vr + (long long)row_i * 128 + 2 * lane);
+            rv[i] = *(const h2 *)((p.v_new && j == r_old ? p.v_new + (long long)bh * 128 : vr + (long long)row_i * 128) + 2 * lane);
         }
         const int nv = rcnt - gi * 16;
         float mr, lr, ores[kMaxG][2];

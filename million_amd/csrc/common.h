@@ -29,6 +29,12 @@ struct AttnParams {
     const f16 *v_tab_col;  // prepared V table, col image [c][m][dm]
     const f16 *k_res;
     const f16 *v_res;
+    const f16 *k_new;      // fused append: the new token's K/V rows (bs, nh_k, 1, d), or null
+    const f16 *v_new;
+    f16 *k_res_w;          // writable aliases of k_res / v_res for the fused append
+    f16 *v_res_w;
+    int *dev_lengths_w;    // writable alias of dev_lengths (r += 1 after a fused append)
+    int *ws_cnt2;          // per-batch second-level ticket
     f16 *out;
     float *ws_part;
     int *ws_cnt;
@@ -181,7 +187,18 @@ __device__ __forceinline__ void publish_and_merge(const AttnParams &p, int b, in
             p.out[((long long)b * p.nh + hk * G + g) * d + (e - g * d)] = (f16)acc;
         }
     }
-    if (tid == 0) __hip_atomic_store(p.ws_cnt + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        __hip_atomic_store(p.ws_cnt + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // fused append with device-resident lengths: every workgroup of batch b has read its lengths once
+        // all nh_k heads have been merged; the last merger advances r
+        if (p.k_new && p.dev_lengths_w) {
+            const int t2 = __hip_atomic_fetch_add(p.ws_cnt2 + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t2 == p.nh_k - 1) {
+                __hip_atomic_store(p.ws_cnt2 + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.dev_lengths_w[b * 4 + 1] += 1;
+            }
+        }
+    }
 }
 
 struct EncParams {

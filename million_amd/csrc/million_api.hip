@@ -177,7 +177,7 @@ size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
     if (!desc || desc->nh_k <= 0 || desc->nh % desc->nh_k) return 0;
     const int G = desc->nh / desc->nh_k;
     const size_t slot = (size_t)(G * desc->d + 2 * G + 3) / 4 * 4;
-    size_t cnt = (size_t)desc->bs * desc->nh_k * sizeof(int);
+    size_t cnt = (size_t)desc->bs * (desc->nh_k + 1) * sizeof(int);
     cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
     return cnt + (size_t)desc->bs * desc->nh_k * (kMaxSplits + 1) * slot * sizeof(float);
 }
@@ -195,13 +195,19 @@ int million_attn_kernel_kind(const million_attn_desc *desc) {
     return (!g_force_generic && attn_mfma_supported(p)) ? 1 : 0;
 }
 
-int million_pq_decode_attn(const million_attn_desc *desc, const void *q, const void *k_codes, const void *v_codes,
-                           const void *k_page_ids, const void *v_page_ids, const void *k_cents_prepared, const void *v_cents_prepared,
-                           const void *k_resid, const void *v_resid, void *out, void *workspace,
-                           size_t workspace_bytes, million_stream_t stream) {
+static int attn_impl(const million_attn_desc *desc, const void *q, const void *k_new, const void *v_new,
+                     const void *k_codes, const void *v_codes,
+                     const void *k_page_ids, const void *v_page_ids, const void *k_cents_prepared, const void *v_cents_prepared,
+                     const void *k_resid, const void *v_resid, void *out, void *workspace,
+                     size_t workspace_bytes, million_stream_t stream) {
     AttnParams p;
     const int rc = fill_attn_params(desc, p);
     if (rc != MILLION_OK) return rc;
+    if ((k_new == nullptr) != (v_new == nullptr)) { set_error("attn: k_new and v_new must both be given"); return MILLION_ERR_ARG; }
+    if (k_new) {
+        if (!p.dev_lengths && p.r >= p.rcap) { set_error("attn: fused append into a full window (r=%d, cap=%d)", p.r, p.rcap); return MILLION_ERR_ARG; }
+        if (((uintptr_t)k_new | (uintptr_t)v_new) & 15) { set_error("attn: k_new / v_new must be 16-byte aligned"); return MILLION_ERR_ALIGN; }
+    }
     if (!q || !k_cents_prepared || !v_cents_prepared || !k_resid || !v_resid || !out || !workspace) { set_error("attn: null pointer"); return MILLION_ERR_ARG; }
     if (p.T > 0 && (!k_codes || !v_codes)) { set_error("attn: null code pointer with n_tokens=%d", p.T); return MILLION_ERR_ARG; }
     if (p.T > 0 && ((p.k_paged && !k_page_ids) || (p.v_paged && !v_page_ids))) { set_error("attn: paged layout without page ids"); return MILLION_ERR_ARG; }
@@ -220,15 +226,37 @@ int million_pq_decode_attn(const million_attn_desc *desc, const void *q, const v
     p.k_tab = (const f16 *)k_cents_prepared; p.k_tab_col = p.k_tab + tab;
     p.v_tab = (const f16 *)v_cents_prepared; p.v_tab_col = p.v_tab + tab;
     p.k_res = (const f16 *)k_resid; p.v_res = (const f16 *)v_resid; p.out = (f16 *)out;
-    size_t cnt = (size_t)p.bs * p.nh_k * sizeof(int);
+    p.k_new = (const f16 *)k_new; p.v_new = (const f16 *)v_new;
+    p.k_res_w = (f16 *)k_resid; p.v_res_w = (f16 *)v_resid;
+    p.dev_lengths_w = (int *)desc->dev_lengths;
+    size_t cnt = (size_t)p.bs * (p.nh_k + 1) * sizeof(int);
     cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
     p.ws_cnt = (int *)workspace;
+    p.ws_cnt2 = p.ws_cnt + p.bs * p.nh_k;
     p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
     if (!g_force_generic && attn_mfma_supported(p)) return launch_attn_mfma(p, (hipStream_t)stream);
     choose_splits(p, 256);
     p.nslots = p.nsplit + 1;
     return launch_attn_generic(p, (hipStream_t)stream);
+}
+
+int million_pq_decode_attn(const million_attn_desc *desc, const void *q, const void *k_codes, const void *v_codes,
+                           const void *k_page_ids, const void *v_page_ids, const void *k_cents_prepared, const void *v_cents_prepared,
+                           const void *k_resid, const void *v_resid, void *out, void *workspace,
+                           size_t workspace_bytes, million_stream_t stream) {
+    return attn_impl(desc, q, nullptr, nullptr, k_codes, v_codes, k_page_ids, v_page_ids, k_cents_prepared,
+                     v_cents_prepared, k_resid, v_resid, out, workspace, workspace_bytes, stream);
+}
+
+int million_pq_decode_attn_append(const million_attn_desc *desc, const void *q, const void *k_new, const void *v_new,
+                                  const void *k_codes, const void *v_codes, const void *k_page_ids,
+                                  const void *v_page_ids, const void *k_cents_prepared, const void *v_cents_prepared,
+                                  void *k_resid, void *v_resid, void *out, void *workspace, size_t workspace_bytes,
+                                  million_stream_t stream) {
+    if (!k_new || !v_new) { set_error("attn_append: k_new / v_new null"); return MILLION_ERR_ARG; }
+    return attn_impl(desc, q, k_new, v_new, k_codes, v_codes, k_page_ids, v_page_ids, k_cents_prepared,
+                     v_cents_prepared, k_resid, v_resid, out, workspace, workspace_bytes, stream);
 }
 
 int million_residual_append(const void *k_new, const void *v_new, void *k_resid, void *v_resid, int bs, int nh_k,

@@ -7,6 +7,7 @@ raises.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Optional
 
 import torch
@@ -39,18 +40,22 @@ def prepare_cents(cents: torch.Tensor, cache: bool = True) -> torch.Tensor:
     _need_cuda(cents)
     if cents.dtype != torch.float16 or cents.dim() != 3:
         raise RuntimeError(f"codebook must be fp16 (M, C, d_m), got {cents.dtype} {tuple(cents.shape)}")
-    key = (cents.data_ptr(), cents._version, tuple(cents.shape), cents.device.index)
-    if cache and key in _prep_cache:
-        return _prep_cache[key]
+    # Cache keyed on the tensor OBJECT (weak reference) + its version counter: a data_ptr key would hand a
+    # stale table to a new codebook that happens to be allocated where a freed one lived.
+    key = id(cents)
+    if cache:
+        hit = _prep_cache.get(key)
+        if hit is not None and hit[0]() is cents and hit[1] == cents._version:
+            return hit[2]
     lib = L.load()
     c = cents.contiguous()
     M, C, dm = c.shape
     out = torch.empty(lib.million_prepared_cents_bytes(M, C, dm) // 2, dtype=torch.float16, device=c.device)
     L.check(lib.million_prepare_cents(c.data_ptr(), M, C, dm, out.data_ptr(), _stream()), "million_prepare_cents")
     if cache:
-        if len(_prep_cache) > 64:
-            _prep_cache.clear()
-        _prep_cache[key] = out
+        for k in [k for k, v in _prep_cache.items() if v[0]() is None]:
+            del _prep_cache[k]
+        _prep_cache[key] = (weakref.ref(cents), cents._version, out)
     return out
 
 
@@ -146,7 +151,8 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
                    n_tokens: Optional[int] = None, resid_start: int = 0,
                    k_page_ids: Optional[torch.Tensor] = None, v_page_ids: Optional[torch.Tensor] = None,
                    page_size: int = 0, out: Optional[torch.Tensor] = None,
-                   dev_lengths: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   dev_lengths: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                   k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One fused launch: score/softmax/value-reconstruct over the code store + residual window + merge.
 
     A side is row-major when its page ids are None: codes (bs, nh_k, T_cap, M) u8 — the reference's
@@ -196,6 +202,21 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
         out = torch.empty_like(q)
     ws = workspace if workspace is not None else attn_workspace(desc, q.device)
     lib = L.load()
+    if k_new is not None:
+        # fused residual-window append: r = valid rows BEFORE the call; the new row becomes row r
+        _need_cuda(k_new, v_new)
+        bs_, nh_ = q.shape[0], q.shape[1]
+        if k_new.shape != (bs_, nh_k, 1, q.shape[3]) or v_new is None or v_new.shape != k_new.shape:
+            raise RuntimeError("pq_decode_attn: k_new / v_new must be (bs, nh_k, 1, d)")
+        if k_new.dtype != torch.float16 or v_new.dtype != torch.float16:
+            raise RuntimeError("pq_decode_attn: k_new / v_new must be fp16")
+        k_new, v_new = k_new.contiguous(), v_new.contiguous()
+        L.check(lib.million_pq_decode_attn_append(ctypes.byref(desc), q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),
+                                                  _ptr(k_codes), _ptr(v_codes), _ptr(k_page_ids), _ptr(v_page_ids),
+                                                  k_prep.data_ptr(), v_prep.data_ptr(), k_res.data_ptr(),
+                                                  v_res.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  _stream()), "million_pq_decode_attn_append")
+        return out
     L.check(lib.million_pq_decode_attn(ctypes.byref(desc), q.data_ptr(), _ptr(k_codes), _ptr(v_codes),
                                        _ptr(k_page_ids), _ptr(v_page_ids),
                                        k_prep.data_ptr(), v_prep.data_ptr(), k_res.data_ptr(), v_res.data_ptr(),

@@ -241,13 +241,13 @@ class DynamicPQCache(_CacheBase):
             self._append_codes((self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx]), layer_idx, Lt)
             self.residualed_tokens[layer_idx] = 0
         r = self.residualed_tokens[layer_idx]
-        ops.residual_append(key_states, value_states, self.key_residual_cache[layer_idx],
-                            self.value_residual_cache[layer_idx], r)       # :304-312
         self.residualed_tokens[layer_idx] = r + 1
         self.seen_tokens[layer_idx] += 1
+        # append (:304-312) + attention (:314-326) in ONE launch
         return ops.pq_decode_attn(query_states, self._k_store[layer_idx], self._v_store[layer_idx], self._kprep,
                                   self._vprep, self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx],
-                                  r + 1, M=self.M, C=self.C, n_tokens=self._T[layer_idx])   # :314-326
+                                  r, M=self.M, C=self.C, n_tokens=self._T[layer_idx], k_new=key_states,
+                                  v_new=value_states)
 
     @property
     def pq_cache_size(self):
@@ -375,12 +375,12 @@ class PagedPQCache(_CacheBase):
             desc = ops.make_attn_desc(query_states, self.key_residual_cache[layer_idx], nh_k=self.num_key_value_heads,
                                       M=self.M, C=self.C, n_tokens=0, r=0)
             self._ws = torch.zeros(L.load().million_attn_workspace_bytes(desc), dtype=torch.uint8, device=self.device)
-        ops.residual_append(key_states, value_states, self.key_residual_cache[layer_idx],
-                            self.value_residual_cache[layer_idx], r, rs, dev_lengths=dl)   # :377-380
         self.residualed_tokens[layer_idx] = r + 1
         self.seen_tokens[layer_idx] += 1
+        # append (:377-380) + attention (:386) in ONE launch: the new row is attended to and parked in the window
         return ops.pq_decode_attn(query_states, self.key_page_pool, self.value_page_pool, self._kprep, self._vprep,
-                                  self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], r + 1,
+                                  self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], r,
+                                  k_new=key_states, v_new=value_states,
                                   M=self.M, C=self.C, n_tokens=self.max_tokens if use_dev_lengths else self._T[layer_idx],
                                   resid_start=rs, k_page_ids=self.page_ids[layer_idx],
                                   v_page_ids=self.page_ids[layer_idx], page_size=self.page_size, out=out,

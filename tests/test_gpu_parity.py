@@ -254,3 +254,66 @@ def test_residual_append_and_dev_lengths(env, oracle):
     c2["k_res"][:, :, 20] = k_new[:, :, 0]; c2["v_res"][:, :, 20] = v_new[:, :, 0]
     c2["r"] = 21
     _check(out.cpu().numpy(), oracle.decode_attn(**c2), "append + device lengths")
+
+
+@pytest.mark.parametrize("paged", [False, True], ids=["rowmajor-generic", "paged-mfma"])
+@pytest.mark.parametrize("use_dl", [False, True], ids=["host-lengths", "device-lengths"])
+def test_fused_append(paged, use_dl, env, oracle):
+    """million_pq_decode_attn_append: the new token's row is attended to AND parked in the window
+    (replaces pq_utils.py:304-312 + :314-326 in one launch); with device-resident lengths r advances."""
+    torch, ops = env
+    bs, nh, nhk, T, r0, ps = 2, 8, 2, 700, 37, 64
+    c = synth.attn_case(55, bs, nh, nhk, 128, 64, 256, T, r0)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    rs = np.random.RandomState(2)
+    start = 100 if paged else 0
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    kw = {}
+    if paged:
+        vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+        kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+        ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+        kc, vc = torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda()
+        kw = dict(k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T)
+    else:
+        kc, vc = t["k_codes"], t["v_codes"]
+    lengths = torch.tensor([[T, r0, start, 0]] * bs, dtype=torch.int32, device="cuda") if use_dl else None
+    k_hist, v_hist = c["k_res"].copy(), c["v_res"].copy()
+    r = r0
+    for step in range(3):
+        k_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        v_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0 if use_dl else r, M=64, C=256, resid_start=start,
+                                 dev_lengths=lengths, k_new=torch.from_numpy(k_new).cuda(),
+                                 v_new=torch.from_numpy(v_new).cuda(), **kw)
+        torch.cuda.synchronize()
+        k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
+        r += 1
+        c2 = dict(c, k_res=k_hist, v_res=v_hist, r=r)
+        _check(out.cpu().numpy(), oracle.decode_attn(**c2), f"fused append step {step}")
+    # the rows were parked in the ring at (start + r0 + i) % cap
+    got = torch.roll(kr, -start, dims=2).cpu().numpy()
+    np.testing.assert_array_equal(got[:, :, r0:r], k_hist[:, :, r0:r])
+    if use_dl:
+        assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
+
+
+def test_prepared_codebook_cache_is_not_keyed_on_address(env, oracle):
+    """Regression: a new codebook allocated where a freed one lived must not reuse its prepared table."""
+    torch, ops = env
+    import bindings
+    c = synth.attn_case(91, 1, 8, 2, 128, 64, 256, 300, 9)
+    t = _dev(torch, c)
+    fn = bindings.flash_decoding_allocated_buffer_f16u8_Ns16Lt128d128M64C256
+    po = torch.empty(1, 8, 17, 128, dtype=torch.float16, device="cuda")
+    pl = torch.empty(1, 8, 17, dtype=torch.float16, device="cuda")
+    for seed in range(4):
+        rs = np.random.RandomState(seed)
+        kc = rs.standard_normal((64, 256, 2)).astype(np.float16)
+        c2 = dict(c, k_cents=kc)
+        kct = torch.from_numpy(kc).cuda()          # freed at the end of the iteration: the address is reused
+        out = fn(t["q"], t["k_codes"], t["v_codes"], kct, t["v_cents"], t["k_res"], t["v_res"], c["r"], po, pl)
+        _check(out.cpu().numpy(), oracle.decode_attn(**c2), f"codebook {seed}")
+        del kct
