@@ -160,7 +160,8 @@ int million_pq_decode_attn_append(const million_attn_desc *desc, const void *q, 
                                   const void *v_cents_prepared, void *k_resid, void *v_resid, void *out,
                                   void *workspace, size_t workspace_bytes, million_stream_t stream);
 
-/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = MFMA fast path, 0 = generic. */
+/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = MFMA fast path, 2 = MFMA fast path
+ * after transposing row-major V codes into workspace scratch (one extra launch), 0 = generic. */
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Force the generic kernel (A/B measurements and tests): 0 = auto (default), 1 = generic only. */
 void million_set_force_generic(int on);

@@ -71,67 +71,64 @@ __device__ __forceinline__ v8f16 as_v8f16(unsigned a, unsigned b, unsigned c, un
 // Page ids come through the scalar cache in ONE asm statement (issue + wait): hipcc does not pick s_load
 // for them by itself, and a vector load of an id would sit in the vmcnt queue in front of the codes.
 struct PidPair { long long k, v; int k32, v32; };
+__device__ __forceinline__ void load_pids4(const AttnParams &p, int bh, const int (&page)[4], PidPair (&o)[4]);
 
 __device__ __forceinline__ PidPair load_pids(const AttnParams &p, int bh, int page) {
-    const unsigned idx = (unsigned)(bh * p.n_pages_cap + page);      // wave-uniform
-    PidPair o;
-    o.k = 0; o.k32 = 0; o.v32 = 0;
-    if (p.ids64) {
-        if (p.k_paged)
-            asm volatile("s_load_dwordx2 %0, %2, %4\n\ts_load_dwordx2 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(o.k), "=&s"(o.v) : "s"(p.k_ids64), "s"(p.v_ids64), "s"(idx * 8u) : "memory");
-        else
-            asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(o.v) : "s"(p.v_ids64), "s"(idx * 8u) : "memory");
-    } else {
-        int k32 = 0, v32;
-        if (p.k_paged)
-            asm volatile("s_load_dword %0, %2, %4\n\ts_load_dword %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(k32), "=&s"(v32) : "s"(p.k_ids32), "s"(p.v_ids32), "s"(idx * 4u) : "memory");
-        else
-            asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(v32) : "s"(p.v_ids32), "s"(idx * 4u) : "memory");
-        o.k = k32;
-        o.v = v32;
-    }
-    return o;
+    int pg[kRing] = {page, page, page, page};
+    PidPair o[kRing];
+    load_pids4(p, bh, pg, o);
+    return o[0];
 }
 
-// The page ids of the ring's kRing first units: ONE scalar round trip, issued early (issue_pids4) and
-// waited for just before the code loads need them (wait_pids4).  Between the two statements the values
-// are in flight: nothing may read them (checked in the ISA: no s_mov of these SGPRs in between).
-__device__ __forceinline__ void issue_pids4(const AttnParams &p, int bh, const int (&page)[kRing], PidPair (&o)[kRing]) {
+// The page ids of the ring's kRing first units: ONE scalar round trip.  Issue and wait live in the SAME asm
+// statement on purpose: an earlier version split them to overlap the latency and hipcc, on an unrelated
+// edit, placed SGPR copies between the two statements — copies of values still in flight — which sent
+// wild addresses to the code loads.  The statement sits after the independent vector loads have been
+// issued, so the scalar latency still overlaps with them.
+__device__ __forceinline__ void load_pids4(const AttnParams &p, int bh, const int (&page)[kRing], PidPair (&o)[kRing]) {
     unsigned off[kRing];
 #pragma unroll
-    for (int k = 0; k < kRing; ++k) off[k] = (unsigned)(bh * p.n_pages_cap + page[k]) * (p.ids64 ? 8u : 4u);
-#pragma unroll
     for (int k = 0; k < kRing; ++k) { o[k].k = 0; o[k].v = 0; o[k].k32 = 0; o[k].v32 = 0; }
-    if (p.ids64) {
+    if (p.v_identity && !p.k_paged) {           // dense scratch pages + row-major K: no id table at all
 #pragma unroll
-        for (int k = 0; k < kRing; ++k) {
-            asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(o[k].v) : "s"(p.v_ids64), "s"(off[k]));
-            if (p.k_paged) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(o[k].k) : "s"(p.k_ids64), "s"(off[k]));
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kRing; ++k) {
-            asm volatile("s_load_dword %0, %1, %2" : "=s"(o[k].v32) : "s"(p.v_ids32), "s"(off[k]));
-            if (p.k_paged) asm volatile("s_load_dword %0, %1, %2" : "=s"(o[k].k32) : "s"(p.k_ids32), "s"(off[k]));
-        }
+        for (int k = 0; k < kRing; ++k) o[k].v = bh * p.n_pages_cap + page[k];
+        return;
     }
-}
-__device__ __forceinline__ void wait_pids4(const AttnParams &p, PidPair (&o)[kRing]) {
-    if (p.ids64) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+s"(o[0].k), "+s"(o[0].v), "+s"(o[1].k), "+s"(o[1].v), "+s"(o[2].k), "+s"(o[2].v), "+s"(o[3].k), "+s"(o[3].v)
-                     :: "memory");
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+s"(o[0].k32), "+s"(o[0].v32), "+s"(o[1].k32), "+s"(o[1].v32), "+s"(o[2].k32), "+s"(o[2].v32),
-                       "+s"(o[3].k32), "+s"(o[3].v32)
-                     :: "memory");
 #pragma unroll
-        for (int k = 0; k < kRing; ++k) { o[k].k = o[k].k32; o[k].v = o[k].v32; }
+    for (int k = 0; k < kRing; ++k) off[k] = (unsigned)(bh * p.n_pages_cap + page[k]) * (p.ids64 ? 8u : 4u);
+    if (p.ids64) {
+        long long v0, v1, v2, v3;
+        asm volatile("s_load_dwordx2 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\t"
+                     "s_load_dwordx2 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                     : "s"(p.v_ids64), "s"(off[0]), "s"(off[1]), "s"(off[2]), "s"(off[3]) : "memory");
+        o[0].v = v0; o[1].v = v1; o[2].v = v2; o[3].v = v3;
+        if (p.k_paged) {
+            asm volatile("s_load_dwordx2 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\t"
+                         "s_load_dwordx2 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                         : "s"(p.k_ids64), "s"(off[0]), "s"(off[1]), "s"(off[2]), "s"(off[3]) : "memory");
+            o[0].k = v0; o[1].k = v1; o[2].k = v2; o[3].k = v3;
+        }
+    } else {
+        int v0, v1, v2, v3;
+        if (p.v_identity) {
+            v0 = bh * p.n_pages_cap + page[0]; v1 = bh * p.n_pages_cap + page[1];
+            v2 = bh * p.n_pages_cap + page[2]; v3 = bh * p.n_pages_cap + page[3];
+        } else {
+            asm volatile("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\t"
+                         "s_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                         : "s"(p.v_ids32), "s"(off[0]), "s"(off[1]), "s"(off[2]), "s"(off[3]) : "memory");
+        }
+        o[0].v = v0; o[1].v = v1; o[2].v = v2; o[3].v = v3;
+        if (p.k_paged) {
+            asm volatile("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\t"
+                         "s_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                         : "s"(p.k_ids32), "s"(off[0]), "s"(off[1]), "s"(off[2]), "s"(off[3]) : "memory");
+            o[0].k = v0; o[1].k = v1; o[2].k = v2; o[3].k = v3;
+        }
     }
 }
 
@@ -352,7 +349,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     //      codebook and q loads (which need no length) have been issued ----
     typedef int v4i __attribute__((ext_vector_type(4)));
     v4i dl = {p.T, p.r, p.rstart, 0};
-    if (p.dev_lengths) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u));
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
     MILLION_STAMP(p, 0);
     const int q4 = lane >> 4, c16 = lane & 15;
@@ -384,7 +380,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             tab[i] = src[tid];
         }
     }
-    if (p.dev_lengths) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dl)::"memory");
+    if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4), after q and the tables have been requested
+        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
     int T = dl[0] < p.T ? dl[0] : p.T;     // the host value is the bound the grid was sized for
     const int r_old = dl[1], rstart = dl[2];
     const int r = r_old + (p.k_new ? 1 : 0);       // fused append: the new token is window row r_old
@@ -400,15 +397,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     const int T_ld = T > 0 ? T : 1;
     const int t_last = (T_ld - 1) & ~31;
 #define UNIT_T(j) ((j) < n_mine ? t_begin + 32 * (wave + (j) * kNW) : t_last)
-    // page ids of the ring's first units: scalar loads issued here, waited for after the residual rows
-    // have been requested
-    int pg[kRing];
-    PidPair pid4[kRing];
-    if (HAS_CODES) {
-#pragma unroll
-        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
-        issue_pids4(p, bh, pg, pid4);
-    }
 
     // ---- residual window rows of this split: j = split, split + nsplit, ... < r; 16 rows per group.
     //      Groups 0..kResWaves-1 (all of them unless a split holds > 32 window rows) are requested by waves
@@ -442,7 +430,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 
     UnitCodes ring[kRing];
     if (HAS_CODES) {
-        wait_pids4(p, pid4);
+        int pg[kRing];
+        PidPair pid4[kRing];
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
+        load_pids4(p, bh, pg, pid4);        // one scalar round trip, after every independent load has been issued
 #pragma unroll
         for (int k = 0; k < kRing; ++k) load_unit_pid(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
     }
@@ -656,9 +648,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
 }
 
+bool attn_mfma_shape_ok(const AttnParams &p) { return p.d == 128 && p.M == 64 && p.C == 256 && p.G <= kMaxG; }
+
 bool attn_mfma_supported(const AttnParams &p) {
-    return p.d == 128 && p.M == 64 && p.C == 256 && p.v_paged && p.G <= kMaxG &&
-           (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
+    return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
 }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {

@@ -43,6 +43,7 @@ struct AttnParams {
     int T, r, rstart, rcap;
     long long res_sb, res_sh, k_sb, k_sh, v_sb, v_sh;
     int k_paged, v_paged, page_size, ps_shift, n_pages_cap, ids64;
+    int v_identity;  // V pages are a dense scratch pool: page id = bh * n_pages_cap + page (no id table)
     int nsplit;      // code splits per (b, hk)
     int nslots;      // partial slots per (b, hk)
     int split_len;   // tokens per split
@@ -79,6 +80,7 @@ __device__ __forceinline__ long long k_page_id(const AttnParams &p, int bh, int 
 }
 __device__ __forceinline__ long long v_page_id(const AttnParams &p, int bh, int page) {
     const long long idx = (long long)bh * p.n_pages_cap + page;
+    if (p.v_identity) return idx;
     return p.ids64 ? p.v_ids64[idx] : (long long)p.v_ids32[idx];
 }
 
@@ -219,6 +221,7 @@ struct EncParams {
 int launch_attn_generic(const AttnParams &p, hipStream_t s);
 int launch_attn_mfma(const AttnParams &p, hipStream_t s);
 int launch_encode(const EncParams &p, hipStream_t s);
+bool attn_mfma_shape_ok(const AttnParams &p);
 bool attn_mfma_supported(const AttnParams &p);
 void set_error(const char *fmt, ...);
 

@@ -70,6 +70,49 @@ __global__ void lengths_advance_kernel(int *dl, int bs, int n, int cap) {
     }
 }
 
+// ---- row-major V codes (bs, nh_k, T, M) -> dense transposed pages (bh * n_pages + page, M, 64) ----
+// The reference's production call passes V row-major (Interface.template.cu:30); the MFMA kernel wants
+// 16 consecutive tokens of one subspace in one 16-byte load.  One workgroup per page: 64 x M tile
+// through LDS.  Tokens >= T of the last page are zero-filled.
+__global__ __launch_bounds__(256) void codes_transpose_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                              int nh_k, int T, int M, long long sb, long long sh,
+                                                              int n_pages) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * (64 + 16)];      // M <= 64, rows padded
+    const int page = blockIdx.x, bh = blockIdx.y;
+    const int b = bh / nh_k, hk = bh % nh_k;
+    const uint8_t *s0 = src + b * sb + hk * sh;
+    const int chunks = M / 16;                                                 // 16-byte chunks per row
+    for (int i = threadIdx.x; i < 64 * chunks; i += 256) {
+        const int tok = i / chunks, ch = i % chunks;
+        const int t = page * 64 + tok;
+        uint4 v = {0, 0, 0, 0};
+        if (t < T) v = *(const uint4 *)(s0 + (long long)t * M + ch * 16);
+        *(uint4 *)(tile + tok * 80 + ch * 16) = v;
+    }
+    __syncthreads();
+    uint8_t *d0 = dst + ((long long)bh * n_pages + page) * M * 64;
+    for (int i = threadIdx.x; i < M * 4; i += 256) {
+        const int m = i >> 2, tq = i & 3;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x |= (uint32_t)tile[(tq * 16 + j * 4 + k) * 80 + m] << (8 * k);
+            w[j] = x;
+        }
+        *(uint4 *)(d0 + m * 64 + tq * 16) = uint4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+static size_t attn_partial_bytes(int bs, int nh_k, int G, int d) {
+    const size_t slot = (size_t)(G * d + 2 * G + 3) / 4 * 4;
+    size_t cnt = (size_t)bs * (nh_k + 1) * sizeof(int);
+    cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
+    size_t b = cnt + (size_t)bs * nh_k * (kMaxSplits + 1) * slot * sizeof(float);
+    return (b + 255) / 256 * 256;
+}
+
 static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     if (!desc || desc->struct_size != sizeof(million_attn_desc)) { set_error("attn: bad desc / struct_size"); return MILLION_ERR_ARG; }
     memset(&p, 0, sizeof(p));
@@ -176,10 +219,11 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
 size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
     if (!desc || desc->nh_k <= 0 || desc->nh % desc->nh_k) return 0;
     const int G = desc->nh / desc->nh_k;
-    const size_t slot = (size_t)(G * desc->d + 2 * G + 3) / 4 * 4;
-    size_t cnt = (size_t)desc->bs * (desc->nh_k + 1) * sizeof(int);
-    cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
-    return cnt + (size_t)desc->bs * desc->nh_k * (kMaxSplits + 1) * slot * sizeof(float);
+    size_t bytes = attn_partial_bytes(desc->bs, desc->nh_k, G, desc->d);
+    // row-major V on the MFMA shapes: room for the transposed copy of the V codes (64-token pages)
+    if (desc->v_layout == MILLION_KV_ROWMAJOR && desc->k_layout == MILLION_KV_ROWMAJOR && desc->n_tokens > 0 && desc->M > 0)
+        bytes += (size_t)desc->bs * desc->nh_k * ((desc->n_tokens + 63) / 64) * desc->M * 64;
+    return bytes;
 }
 
 int million_workspace_init(void *workspace, size_t bytes, million_stream_t stream) {
@@ -192,7 +236,9 @@ int million_workspace_init(void *workspace, size_t bytes, million_stream_t strea
 int million_attn_kernel_kind(const million_attn_desc *desc) {
     AttnParams p;
     if (fill_attn_params(desc, p) != MILLION_OK) return -1;
-    return (!g_force_generic && attn_mfma_supported(p)) ? 1 : 0;
+    if (g_force_generic) return 0;
+    if (attn_mfma_supported(p)) return 1;
+    return (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) ? 2 : 0;   // 2 = transpose + MFMA
 }
 
 static int attn_impl(const million_attn_desc *desc, const void *q, const void *k_new, const void *v_new,
@@ -236,6 +282,17 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
     if (!g_force_generic && attn_mfma_supported(p)) return launch_attn_mfma(p, (hipStream_t)stream);
+    if (!g_force_generic && attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) {
+        // reference 10-arg layout on the MFMA shapes: transpose V into scratch pages, then the fast kernel
+        uint8_t *scratch = (uint8_t *)workspace + attn_partial_bytes(p.bs, p.nh_k, p.G, p.d);
+        const int n_pages = (p.T + 63) / 64;
+        hipLaunchKernelGGL(codes_transpose_kernel, dim3(n_pages, p.bs * p.nh_k), dim3(256), 0, (hipStream_t)stream,
+                           p.v_codes, scratch, p.nh_k, p.T, p.M, p.v_sb, p.v_sh, n_pages);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+        p.v_codes = scratch; p.v_paged = 1; p.v_identity = 1; p.page_size = 64; p.ps_shift = 6; p.n_pages_cap = n_pages;
+        return launch_attn_mfma(p, (hipStream_t)stream);
+    }
     choose_splits(p, 256);
     p.nslots = p.nsplit + 1;
     return launch_attn_generic(p, (hipStream_t)stream);

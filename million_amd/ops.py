@@ -112,7 +112,9 @@ def attn_workspace(desc: L.AttnDesc, device: torch.device) -> torch.Tensor:
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.zeros(need, dtype=torch.uint8, device=device)   # zeroed once; every call leaves it ready
+        # zeroed once; every call leaves it ready.  Grown with headroom: the row-major path keeps a
+        # transposed copy of the V codes here, which grows with the context.
+        ws = torch.zeros(need + need // 2, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
 

@@ -211,6 +211,7 @@ class DynamicPQCache(_CacheBase):
         self.seen_tokens = [0] * self.layer_num
         self.residualed_tokens = [0] * self.layer_num
         self._T = [0] * self.layer_num
+        self._ws = None
 
     # views with the reference's shapes
     @property
@@ -243,11 +244,16 @@ class DynamicPQCache(_CacheBase):
         r = self.residualed_tokens[layer_idx]
         self.residualed_tokens[layer_idx] = r + 1
         self.seen_tokens[layer_idx] += 1
+        if self._ws is None:      # sized once for max_tokens (partials + transposed-V scratch of the row-major path)
+            desc = ops.make_attn_desc(query_states, self.key_residual_cache[layer_idx], nh_k=self.num_key_value_heads,
+                                      M=self.M, C=self.C, n_tokens=self.max_tokens, r=0,
+                                      k_codes=self._k_store[layer_idx], v_codes=self._v_store[layer_idx])
+            self._ws = torch.zeros(L.load().million_attn_workspace_bytes(desc), dtype=torch.uint8, device=self.device)
         # append (:304-312) + attention (:314-326) in ONE launch
         return ops.pq_decode_attn(query_states, self._k_store[layer_idx], self._v_store[layer_idx], self._kprep,
                                   self._vprep, self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx],
                                   r, M=self.M, C=self.C, n_tokens=self._T[layer_idx], k_new=key_states,
-                                  v_new=value_states)
+                                  v_new=value_states, workspace=self._ws)
 
     @property
     def pq_cache_size(self):

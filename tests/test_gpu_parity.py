@@ -317,3 +317,38 @@ def test_prepared_codebook_cache_is_not_keyed_on_address(env, oracle):
         out = fn(t["q"], t["k_codes"], t["v_codes"], kct, t["v_cents"], t["k_res"], t["v_res"], c["r"], po, pl)
         _check(out.cpu().numpy(), oracle.decode_attn(**c2), f"codebook {seed}")
         del kct
+
+
+def test_dynamic_cache_decode_sequence(env, oracle):
+    """DynamicPQCache (row-major store, flush all Lt=128 rows when full, pq_utils.py:281-328) over a
+    prefill + 300 decode steps: token accounting == the policy oracle, outputs == the attention oracle with
+    codes produced by the encode oracle."""
+    torch, ops = env
+    from million_amd.pq_cache import DynamicPQCache
+    bs, nh, nhk, d, M, C = 1, 8, 2, 128, 64, 256
+    rs = np.random.RandomState(3)
+    ck = rs.standard_normal((M, C, 2)).astype(np.float16)
+    cv = rs.standard_normal((M, C, 2)).astype(np.float16)
+    n_prompt, n_dec = 100, 300
+    K = rs.standard_normal((bs, nhk, n_prompt + n_dec, d)).astype(np.float16)
+    V = rs.standard_normal((bs, nhk, n_prompt + n_dec, d)).astype(np.float16)
+    Q = rs.standard_normal((n_dec, bs, nh, 1, d)).astype(np.float16)
+    cache = DynamicPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, max_tokens=1024)
+    cache.set_cent(torch.from_numpy(ck).cuda(), torch.from_numpy(cv).cuda())
+    Kd, Vd = torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda()
+    cache.prefill(torch.from_numpy(Q[0]).cuda().repeat(1, 1, n_prompt, 1), Kd[:, :, :n_prompt].contiguous(),
+                  Vd[:, :, :n_prompt].contiguous(), 0)
+    pol = oracle.DynamicPolicy(Lt=128, prefill=n_prompt)
+    for i in range(n_dec):
+        t = n_prompt + i
+        out = cache.decoding(torch.from_numpy(Q[i]).cuda(), Kd[:, :, t:t + 1].contiguous(), Vd[:, :, t:t + 1].contiguous(), 0)
+        T, r = pol.step()
+        assert (cache._T[0], cache.residualed_tokens[0]) == (T, r)
+        assert cache.key_cache[0].shape == (bs, nhk, T, M)
+        if i % 37 == 0 or i == n_dec - 1:
+            kc, vc = oracle.pq_encode(K[:, :, :T], ck), oracle.pq_encode(V[:, :, :T], cv)
+            np.testing.assert_array_equal(cache.key_cache[0].cpu().numpy(), kc)
+            kres = np.zeros((bs, nhk, 128, d), np.float16)
+            vres = np.zeros((bs, nhk, 128, d), np.float16)
+            kres[:, :, :r], vres[:, :, :r] = K[:, :, T:T + r], V[:, :, T:T + r]
+            _check(out.cpu().numpy(), oracle.decode_attn(Q[i], kc, vc, ck, cv, kres, vres, r), f"dynamic step {i}")
