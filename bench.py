@@ -78,7 +78,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)     # RCCL; only barrier + max-reduce of the elapsed time
 
-    from million_amd import ops
+    from million_amd import ops, sharding
     from million_amd.pq_cache import PagedPQCache
 
     ops.set_force_generic(args.force_generic)
@@ -136,30 +136,18 @@ def main():
             graphs["flush" if cache.next_step_flushes() else "plain"].replay()
             cache.note_replayed_step()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
     n_flush_steps = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def counted_step():
+        nonlocal n_flush_steps
         n_flush_steps += int(cache.next_step_flushes())
         one_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    tokens = args.steps * bs * world
-    value = tokens / elapsed
+
+    # exactly K steps between barrier + synchronize on both sides; MAX over ranks (million_amd/sharding.py)
+    elapsed = sharding.timed_steps(counted_step, args.steps, torch.cuda.synchronize, dist if world > 1 else None)
+    value, ms_per_step = sharding.aggregate_throughput(bs, args.steps, elapsed, world)
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream ----
     # All (event, launch, event) triplets are enqueued behind a long device-side sleep so that the
@@ -198,7 +186,7 @@ def main():
         line = {
             "metric": "decode tokens/sec @32K ctx, Llama-3.1-8B PQ-KV attention hot path (32 layers), 1xMI355X per request",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 in/out, u8 codes, f32 accumulate", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Llama-3.1-8B shape (32 layers, nh=32, nh_k=8, d=128), "
                                    f"ctx {T0}, PQ M={M} nbits=8, PagedPQCache page 64 / window 128, batch {bs}/GPU; "

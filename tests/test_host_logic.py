@@ -1,0 +1,100 @@
+"""CPU tests of host-side logic: page manager, split/name heuristics, request sharding, and the
+multi-process timing path of bench.py on the gloo backend (world size 2)."""
+import json
+import os
+import socket
+import time
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from million_amd import sharding
+from million_amd.pq_cache import PageManager, l2Ns, nbits2dtype, scalarTypeToStr
+
+
+def test_l2ns_and_names_match_reference_table(golden_dir):
+    man = json.loads((golden_dir / "manifest.json").read_text())
+    for l, ns in man["l2Ns"].items():
+        assert l2Ns(int(l)) == ns
+    for n, dt in man["nbits2dtype"].items():
+        assert str(nbits2dtype(int(n))) == dt
+    assert scalarTypeToStr(torch.float16) == "f16"
+    with pytest.raises(ValueError):
+        scalarTypeToStr(torch.bfloat16)
+
+
+def test_page_manager_semantics():
+    """dynamic_paged_pq_utils.py:137-241: allocate / free / reuse / growth capped by max_pages."""
+    pm = PageManager(page_size=64, initial_pages=4, max_pages=10, M=64)
+    ids = [pm.allocate_page() for _ in range(4)]
+    assert ids == [0, 1, 2, 3] and pm.get_stats()["free_pages"] == 0
+    pm.free_page(2)
+    assert pm.allocate_page() == 2 and pm.page_reuse_count == 1
+    more = pm.allocate_pages(5)                     # forces growth by exactly the missing amount
+    assert len(set(ids + more)) == 9 and pm.current_active_pages == 9
+    assert pm.allocate_page() == 9                  # grows to the cap
+    with pytest.raises(RuntimeError):
+        pm.allocate_page()                          # max_pages reached
+    pm.free_page(12345)                             # unknown id: ignored, as in the reference (:234-236)
+    st = pm.get_stats()
+    assert st["allocated_pages"] == 10 and st["max_pages"] == 10 and st["total_expansions"] >= 2
+    unlimited = PageManager(initial_pages=2, max_pages=None)
+    assert len(unlimited.allocate_pages(200)) == 200
+
+
+def test_shard_requests():
+    # BASELINE configs[3]: 16 requests over 8 GPUs -> 2 per rank
+    assert [len(sharding.shard_requests(16, 8, r)) for r in range(8)] == [2] * 8
+    got = sum((sharding.shard_requests(10, 4, r) for r in range(4)), [])
+    assert got == list(range(10))
+    assert [len(sharding.shard_requests(10, 4, r)) for r in range(4)] == [3, 3, 2, 2]
+    assert sharding.shard_requests(1, 4, 3) == []
+    with pytest.raises(ValueError):
+        sharding.shard_requests(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    done = []
+
+    def step():
+        time.sleep(0.01 * (1 + 2 * rank))       # rank 1 is 3x slower: the job time must be rank 1's
+        done.append(1)
+
+    elapsed = sharding.timed_steps(step, 5, lambda: None, dist)
+    value, ms = sharding.aggregate_throughput(1, 5, elapsed, world)
+    out.put((rank, len(done), elapsed, value, ms, sharding.shard_requests(5, world, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multirank_timing_gloo():
+    """bench.py --gpus N contract: exactly K steps per rank, barrier on both sides, MAX over ranks,
+    value = all ranks' units / that time.  World size 2 on CPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, n0, e0, v0, ms0, s0), (r1, n1, e1, v1, ms1, s1) = res
+    assert n0 == n1 == 5
+    assert e0 == e1 and e0 >= 5 * 0.03 * 0.9            # both ranks report rank 1's (max) time
+    assert v0 == v1 == pytest.approx(10 / e0)
+    assert s0 + s1 == list(range(5))
