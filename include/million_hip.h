@@ -185,6 +185,9 @@ int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int res
 /* Diagnostics only: when `buf` is non-NULL the decode-attention kernels store up to 16 x uint64 realtime-counter
  * stamps (100 MHz) per workgroup at their phase boundaries into buf (grid_size * 16 entries).  NULL = off. */
 void million_debug_set_stamp_buffer(void *buf);
+/* Diagnostics only: runs the kernel's row-swap reductions on one wave: out_max[l] / out_sum[l] = max / sum of
+ * in[l % 16 + 16*k], k = 0..3 (device pointers to 64 floats each). */
+int million_debug_rows_reduce(const float *in64, float *out_max64, float *out_sum64, million_stream_t stream);
 
 #ifdef __cplusplus
 }

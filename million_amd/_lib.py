@@ -51,6 +51,7 @@ SYMBOLS = {
     "million_attn_kernel_kind": (c_i32, [ctypes.POINTER(AttnDesc)]),
     "million_set_force_generic": (None, [c_i32]),
     "million_debug_set_stamp_buffer": (None, [c_vp]),
+    "million_debug_rows_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "million_lengths_advance": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "million_residual_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64,
                                         c_i32, c_i32, c_vp, c_vp]),

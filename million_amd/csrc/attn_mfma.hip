@@ -56,6 +56,43 @@ __device__ __forceinline__ unsigned lds32(unsigned addr) {
     return *(const __attribute__((address_space(3))) unsigned *)(size_t)addr;
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row swaps:
+// pure VALU.  (ds_bpermute-based __shfl_xor goes through the LDS queue, which the code-byte gathers of the
+// other waves keep saturated: a dependent shuffle then costs a microsecond.)
+// NOTE (hipcc, ROCm 7.2): `__builtin_bit_cast(float, v[1])` on an element of an ext_vector (here the pair a
+// permlane swap builtin returns) is mis-lowered to element 0 — seen in the ISA: the row maximum became
+// "row 0" and the row sum 4 x row 0.  The elements are therefore copied to scalars and converted with
+// __uint_as_float.  tests: test_rows_reduce_selfcheck.
+__device__ __forceinline__ unsigned opaque_copy(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ v2u swap16_self(unsigned x) {      // rows {0,0,2,2} of x / rows {1,1,3,3} of x
+    return __builtin_amdgcn_permlane16_swap(x, opaque_copy(x), false, false);
+}
+__device__ __forceinline__ v2u swap32_self(unsigned x) {      // lower half twice / upper half twice
+    return __builtin_amdgcn_permlane32_swap(x, opaque_copy(x), false, false);
+}
+__device__ __forceinline__ float rows_max(float x) {
+    const v2u a = swap16_self(__float_as_uint(x));
+    const unsigned a0 = a[0], a1 = a[1];
+    const float m1 = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+    const v2u b = swap32_self(__float_as_uint(m1));
+    const unsigned b0 = b[0], b1 = b[1];
+    return fmaxf(__uint_as_float(b0), __uint_as_float(b1));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    const v2u a = swap16_self(__float_as_uint(x));
+    const unsigned a0 = a[0], a1 = a[1];
+    const float s1 = __uint_as_float(a0) + __uint_as_float(a1);
+    const v2u b = swap32_self(__float_as_uint(s1));
+    const unsigned b0 = b[0], b1 = b[1];
+    return __uint_as_float(b0) + __uint_as_float(b1);
+}
+__device__ __forceinline__ float lane_bcast(float x, int lane_const) {       // v_readlane -> SGPR operand
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane_const));
+}
 __device__ __forceinline__ v8f16 as_v8f16(unsigned a, unsigned b, unsigned c, unsigned d) {
     v4u t = {a, b, c, d};
     return __builtin_bit_cast(v8f16, t);
@@ -159,73 +196,27 @@ __device__ __forceinline__ void load_unit(const AttnParams &p, int b, int hk, in
     load_unit_pid(p, b, hk, load_pids(p, bh, t_unit >> p.ps_shift), t_unit, T, lane, u);
 }
 
-// Online-softmax update shared by code units and residual groups.  sc[NS]: scaled scores (exp2 domain)
-// of this lane's tokens (-inf where masked).  Returns probabilities in sc.  Lanes with the same
-// (lane & 15) hold the same query head; the max is reduced over the four 16-lane rows.
-template <int NS>
-__device__ __forceinline__ void softmax_update(float (&sc)[NS], float &m_run, float &l_run, v16f32 (&O)[2][2],
-                                               int G, int lane) {
-    float mx = sc[0];
-#pragma unroll
-    for (int i = 1; i < NS; ++i) mx = fmaxf(mx, sc[i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // m_new is finite unless every token so far was masked; exp2(-inf - finite) = 0
-    const float m_safe = m_new > -INFINITY ? m_new : 0.f;
-    const float alpha = fast_exp2(m_run - m_safe);
-    if (__any(m_new > m_run && m_run > -INFINITY)) {
-        // some head's running max moved: rescale the accumulators (rows of O are heads)
-        // alpha of head g sits in lane g; O rows: lanes < 32 hold heads rho, lanes >= 32 heads 4 + rho
-        const int hi4 = (lane >> 5) << 2;
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho) {
-            const float f = (hi4 + rho < G) ? __shfl(alpha, hi4 + rho, 64) : 1.0f;
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
-        }
-    }
-    float ls = 0.f;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const float pe = fast_exp2(sc[i] - m_safe);
-        sc[i] = pe;
-        ls += pe;
-    }
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
-}
-
-// One 32-token unit: scores (MFMA 16x16x32), online softmax, probabilities -> value MFMA (32x32x16).
+// Scores of one 32-token unit (MFMA 16x16x32): sc[g2*4 + rho] = scaled score (exp2 domain) of token
+// 16*g2 + 4*q' + rho for the head of this lane's column (lane & 15); -inf beyond the split's last token.
 template <bool MASK>
-__device__ __forceinline__ void compute_unit(const UnitCodes &cur, const v8f16 (&qb)[4],
-                                             int t_unit, int t_end, float scale_log2e, int G, int lane,
-                                             unsigned kbase, unsigned vconst0, unsigned vconst1,
-                                             float &m_run, float &l_run, v16f32 (&O)[2][2]) {
+__device__ __forceinline__ void score_unit(const v4u (&kc)[2], const v8f16 (&qb)[4], int t_unit, int t_end,
+                                           float scale_log2e, int lane, unsigned kbase, float (&sc)[8]) {
     const int q4 = lane >> 4;
-    // ---- scores: D[g2][rho] = S[token 16*g2 + 4*q' + rho][head lane&15] ----
-    v4f32 D[2];
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-        D[g2] = v4f32{0.f, 0.f, 0.f, 0.f};
+        v4f32 D = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const unsigned w = cur.k[g2][s];
+            const unsigned w = kc[g2][s];
             const unsigned a0 = lds32(kbase + (4 * s + 0) * 1024 + ((w & 0xffu) << 2));
             const unsigned a1 = lds32(kbase + (4 * s + 1) * 1024 + (((w >> 8) & 0xffu) << 2));
             const unsigned a2 = lds32(kbase + (4 * s + 2) * 1024 + (((w >> 16) & 0xffu) << 2));
             const unsigned a3 = lds32(kbase + (4 * s + 3) * 1024 + ((w >> 24) << 2));
-            D[g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(a0, a1, a2, a3), qb[s], D[g2], 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(a0, a1, a2, a3), qb[s], D, 0, 0, 0);
         }
-    }
-    float sc[8];
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
         for (int rho = 0; rho < 4; ++rho) {
-            const float v = D[g2][rho] * scale_log2e;
+            const float v = D[rho] * scale_log2e;
             if (MASK) {
                 const int tok = t_unit + 16 * g2 + 4 * q4 + rho;
                 sc[g2 * 4 + rho] = tok < t_end ? v : -INFINITY;
@@ -233,16 +224,21 @@ __device__ __forceinline__ void compute_unit(const UnitCodes &cur, const v8f16 (
                 sc[g2 * 4 + rho] = v;
             }
         }
-    softmax_update<8>(sc, m_run, l_run, O, G, lane);
+    }
+}
 
-    // ---- probabilities -> A operand of the value MFMA (rows = heads, K = 16 tokens per step) ----
+// Values of one 32-token unit: O[n][kk] (rows = heads, cols = subspaces 32n..32n+31) += P (heads x tokens) * Vhat.
+// pr[g2*4 + rho] = probability of token 16*g2 + 4*q' + rho for the head of this lane's column.
+__device__ __forceinline__ void value_unit(const v4u (&vc)[2], const float (&pr)[8], unsigned vconst0, unsigned vconst1,
+                                           v16f32 (&O)[2][2]) {
+    // probabilities -> A operand of the value MFMA (rows = heads, K = 16 tokens per step)
     // pk[g2][i]: tokens 16*g2 + 4*q' + {2i, 2i+1} as packed fp16
     unsigned pk[2][2];
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            h2 t = {(f16)sc[g2 * 4 + 2 * i], (f16)sc[g2 * 4 + 2 * i + 1]};
+            h2 t = {(f16)pr[g2 * 4 + 2 * i], (f16)pr[g2 * 4 + 2 * i + 1]};
             pk[g2][i] = __builtin_bit_cast(unsigned, t);
         }
     // step s uses tokens 16h + 8s + j: rows q' = 2s (j<4) and 2s+1 (j>=4) of group h
@@ -253,20 +249,18 @@ __device__ __forceinline__ void compute_unit(const UnitCodes &cur, const v8f16 (
         // x[0] = {grp0 rows 0,1 | grp1 rows 0,1}  (step 0)   x[1] = {grp0 rows 2,3 | grp1 rows 2,3}  (step 1)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const v2u y = __builtin_amdgcn_permlane16_swap(x[s], x[s], false, false);
+            const v2u y = swap16_self(x[s]);
             // y[0] rows {0,0,2,2} of x[s] ; y[1] rows {1,1,3,3} of x[s]
             P[s][i] = y[0];
             P[s][2 + i] = y[1];
         }
     }
-
-    // ---- values: O[n][kk] (rows = heads, cols = subspaces 32n..32n+31) += P (heads x 16 tokens) * Vhat ----
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const unsigned vconst = n ? vconst1 : vconst0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const unsigned w0 = cur.v[n][2 * s], w1 = cur.v[n][2 * s + 1];
+            const unsigned w0 = vc[n][2 * s], w1 = vc[n][2 * s + 1];
             const unsigned e0 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020400u));
             const unsigned e1 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020500u));
             const unsigned e2 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020600u));
@@ -305,8 +299,7 @@ __device__ __forceinline__ void resid_group(const v4u (&kraw)[4], const h2 (&vro
         sc[rho] = (4 * q4 + rho) < nvalid ? D[rho] * scale_log2e : -INFINITY;
         mx = fmaxf(mx, sc[rho]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows_max(mx);
     const float m_safe = mx > -INFINITY ? mx : 0.f;
     float ls = 0.f;
 #pragma unroll
@@ -314,14 +307,14 @@ __device__ __forceinline__ void resid_group(const v4u (&kraw)[4], const h2 (&vro
         sc[rho] = fast_exp2(sc[rho] - m_safe);
         ls += sc[rho];
     }
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
+    ls = rows_sum(ls);
     m_out = mx;
     l_out = ls;
 #pragma unroll
     for (int g = 0; g < kMaxG; ++g) ores[g][0] = ores[g][1] = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        if (i >= nvalid) break;                 // wave-uniform: typically <= 4 rows per split
         const float v0 = (float)vrow[i][0], v1 = (float)vrow[i][1];
 #pragma unroll
         for (int g = 0; g < kMaxG; ++g)
@@ -365,20 +358,24 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             qb[s] = __builtin_bit_cast(v8f16, t);
         }
     }
-    // ---- both codebooks (16 x 16 B per thread): requested before anything that depends on a length ----
-    // Every workgroup needs the same 128 KiB at the same time: walking the 16 chunks in the same order
-    // would hammer one L2 channel after the other from all CUs, so each workgroup starts at its own chunk.
-    v4u tab[16];
-    const int rot = (blockIdx.x + 5 * blockIdx.y) & 15;
+    // fused append: the new token's K/V row is parked in the window by the last wave of split 0; its two
+    // loads are requested here (oldest loads of that wave) and stored after the first score pass
+    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
+    h2 new_k = {}, new_v = {};
+    if (append_wave) {
+        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
+    }
+    // ---- K codebook (8 x 16 B per thread): requested before anything that depends on a length.  Every
+    //      workgroup needs the same 64 KiB at the same time: each starts at its own chunk so that the CUs
+    //      do not walk the L2 channels in lockstep.  The V codebook is requested AFTER the code ring: the
+    //      score pass needs only K, so V may land behind the first codes. ----
+    v4u tabk[8];
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
     {
         const v4u *ks = (const v4u *)p.k_tab;
-        const v4u *vs = (const v4u *)p.v_tab_col;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ci = (i + rot) & 15;                       // wave-uniform
-            const v4u *src = ci < 8 ? ks + ci * (kNW * 64) : vs + (ci - 8) * (kNW * 64);
-            tab[i] = src[tid];
-        }
+        for (int i = 0; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
     }
     if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4), after q and the tables have been requested
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
@@ -408,6 +405,32 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
     const bool res_wave = wave < kResWaves && wave < rgroups;      // wave-uniform
+
+    // ---- the first code unit of this wave, then the K codebook goes to LDS.  Only these 16 loads (q, K
+    //      codebook, unit 0) are issued before the first barrier: the CU's load path takes a few microseconds
+    //      to accept everything this workgroup requests (64 B/clk), and a wave cannot write its share of the
+    //      codebook while it is still stuck issuing loads. ----
+    UnitCodes ring[kRing];
+    PidPair pid4[kRing];
+    if (HAS_CODES) {
+        int pg[kRing];
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
+        load_pids4(p, bh, pg, pid4);        // one scalar round trip, after q and the K codebook have been requested
+        load_unit_pid(p, b, hk, pid4[0], UNIT_T(0), T_ld, lane, ring[0]);
+    }
+    MILLION_STAMP(p, 7);
+    {
+        v4u *ld = (v4u *)smem;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabk[i];
+    }
+    MILLION_STAMP(p, 8);
+    __syncthreads();     // no LDS-DMA in flight: lgkmcnt(0) + s_barrier, unit 0 stays in flight
+    MILLION_STAMP(p, 1);
+
+    // ---- everything else is requested now and lands while the first scores are computed: the residual rows
+    //      of this wave's group, code units 1..3, the V codebook ----
     v4u rk[4];
     h2 rv[16];
     if (res_wave) {
@@ -427,55 +450,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             rv[i] = *(const h2 *)((p.v_new && j == r_old ? p.v_new + (long long)bh * 128 : vr + (long long)row_i * 128) + 2 * lane);
         }
     }
-
-    UnitCodes ring[kRing];
     if (HAS_CODES) {
-        int pg[kRing];
-        PidPair pid4[kRing];
 #pragma unroll
-        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
-        load_pids4(p, bh, pg, pid4);        // one scalar round trip, after every independent load has been issued
-#pragma unroll
-        for (int k = 0; k < kRing; ++k) load_unit_pid(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
+        for (int k = 1; k < kRing; ++k) load_unit_pid(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
     }
-    if (p.k_new && split == 0 && wave == kNW - 1) {      // fused append: park the new row in the window
-        int row_n = rstart + r_old;
-        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
-        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
-        *(h2 *)(p.k_res_w + o) = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
-        *(h2 *)(p.v_res_w + o) = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
+    v4u tabv[8];
+    {
+        const v4u *vs = (const v4u *)p.v_tab_col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tabv[i] = vs[((i + rot) & 7) * (kNW * 64) + tid];
     }
     MILLION_STAMP(p, 9);
-    // this wave's residual group -> its own softmax partial (m, l, O_res) in LDS.  Its rows are the oldest
-    // loads of the wave, so this runs while the codebooks and the codes are still on their way.
-    if (res_wave) {
-        // opaque use AFTER every load of the prologue has been issued: keeps hipcc from hoisting the
-        // fp16->fp32 conversions (and with them the wait for these rows) above the table / code loads
-        asm volatile("" : "+v"(rk[0]), "+v"(rk[1]), "+v"(rk[2]), "+v"(rk[3]), "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]),
-                          "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]), "+v"(rv[8]), "+v"(rv[9]),
-                          "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]), "+v"(rv[15]));
-        const int nv = rcnt - wave * 16;
-        float mr, lr, ores[kMaxG][2];
-        resid_group(rk, rv, nv < 16 ? nv : 16, qb, p.scale_log2e, G, lane, mr, lr, ores);
-        float *ro = (float *)(smem + kResOut + wave * 4096);
-#pragma unroll
-        for (int g = 0; g < kMaxG; ++g)
-            if (g < G) *(float2 *)(ro + g * 128 + 2 * lane) = float2{ores[g][0], ores[g][1]};
-        if (lane < G) {
-            float *ml = (float *)(smem + kResML) + wave * 16;
-            ml[lane] = mr;
-            ml[8 + lane] = lr;
-        }
-    }
-    MILLION_STAMP(p, 7);
-    {
-        v4u *ld = (v4u *)smem;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ld[((i + rot) & 15) * (kNW * 64) + tid] = tab[i];
-    }
-    MILLION_STAMP(p, 8);
-    __syncthreads();     // no LDS-DMA in flight: lgkmcnt(0) + s_barrier, the code ring stays in flight
-    MILLION_STAMP(p, 1);
     float m_run = -INFINITY, l_run = 0.f;
     v16f32 O[2][2];
 #pragma unroll
@@ -486,31 +471,101 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
     MILLION_STAMP(p, 2);
 
+    // this wave's residual group -> its own softmax partial (m, l, O_res) in LDS; runs between the score pass
+    // and the V-codebook barrier of the first group, when its rows have long arrived
+#define RESID_PARTIAL()                                                                                            \
+    if (res_wave) {                                                                                                \
+        /* opaque use: keeps hipcc from hoisting the fp16->fp32 conversions (and with them the wait for */        \
+        /* these rows) above the loads issued after them */                                                       \
+        asm volatile("" : "+v"(rk[0]), "+v"(rk[1]), "+v"(rk[2]), "+v"(rk[3]), "+v"(rv[0]), "+v"(rv[1]),          \
+                          "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),          \
+                          "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]),      \
+                          "+v"(rv[14]), "+v"(rv[15]));                                                             \
+        const int nv = rcnt - wave * 16;                                                                           \
+        float mr, lr, ores[kMaxG][2];                                                                              \
+        resid_group(rk, rv, nv < 16 ? nv : 16, qb, p.scale_log2e, G, lane, mr, lr, ores);                          \
+        float *ro = (float *)(smem + kResOut + wave * 4096);                                                       \
+        _Pragma("unroll") for (int g = 0; g < kMaxG; ++g)                                                          \
+            if (g < G) *(float2 *)(ro + g * 128 + 2 * lane) = float2{ores[g][0], ores[g][1]};                      \
+        if (lane < G) {                                                                                            \
+            float *ml = (float *)(smem + kResML) + wave * 16;                                                      \
+            ml[lane] = mr;                                                                                         \
+            ml[8 + lane] = lr;                                                                                     \
+        }                                                                                                          \
+    }
 
     const unsigned kbase = (unsigned)q4 * 16u * 1024u;                 // K row image: m = 16*q4 + ...
     const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);        // m = c
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);  // m = 32 + c
 
-    if (HAS_CODES) {
-        // all passes but the last: every unit exists; consume a slot, then refill it unconditionally
-        for (int pass = 0; pass + 1 < n_pass; ++pass) {
-#pragma unroll
-            for (int k = 0; k < kRing; ++k) {
-                const int j = pass * kRing + k;
-                compute_unit<false>(ring[k], qb, t_begin + 32 * (wave + j * kNW), t_end, p.scale_log2e, G, lane, kbase,
-                                    vconst0, vconst1, m_run, l_run, O);
-                load_unit(p, b, hk, bh, UNIT_T(j + kRing), T_ld, lane, ring[k]);
-            }
-        }
-        // last pass: no refills, so the waits count down 12, 8, 4, 0
-#pragma unroll
-        for (int k = 0; k < kRing; ++k) {
-            const int j = (n_pass - 1) * kRing + k;
-            if (n_pass > 0 && j < n_mine)     // the last unit of a split can be partial: masked variant
-                compute_unit<true>(ring[k], qb, t_begin + 32 * (wave + j * kNW), t_end, p.scale_log2e, G, lane, kbase,
-                                   vconst0, vconst1, m_run, l_run, O);
-        }
+    // ---- groups of kRing units: SCORE pass for the whole group (K codebook only), one softmax update per
+    //      group, then the VALUE pass.  The V codebook goes to LDS between the two passes of the first group,
+    //      so the first scores are computed while it is still arriving. ----
+#define GROUP(PASS, MASKV, FIRST, REFILL)                                                                          \
+    {                                                                                                              \
+        float sc[kRing][8];                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < kRing; ++k) {                                                        \
+            const int j = (PASS) * kRing + k;                                                                      \
+            if (HAS_CODES && j < n_mine)                                                                           \
+                score_unit<MASKV>(ring[k].k, qb, t_begin + 32 * (wave + j * kNW), t_end, p.scale_log2e, lane,      \
+                                  kbase, sc[k]);                                                                   \
+            else                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[k][i] = -INFINITY;                                \
+        }                                                                                                          \
+        float mx = sc[0][0];                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < kRing; ++k)                                                          \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) mx = fmaxf(mx, sc[k][i]);                                \
+        mx = rows_max(mx);                                                                                         \
+        const float m_new = fmaxf(m_run, mx);                                                                      \
+        const float m_safe = m_new > -INFINITY ? m_new : 0.f;                                                      \
+        const float alpha = fast_exp2(m_run - m_safe);                                                             \
+        if (!(FIRST) && __any(m_new > m_run && m_run > -INFINITY)) {                                               \
+            /* alpha of head g sits in lane g; O rows: lanes < 32 hold heads rho, lanes >= 32 heads 4 + rho */     \
+            _Pragma("unroll") for (int rho = 0; rho < 4; ++rho) {                                                  \
+                const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;                                         \
+                const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;                                 \
+                const float f = lane < 32 ? flo : fhi;                                                             \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                      \
+                    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;                           \
+            }                                                                                                      \
+        }                                                                                                          \
+        float ls = 0.f;                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < kRing; ++k)                                                          \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
+                sc[k][i] = fast_exp2(sc[k][i] - m_safe);                                                           \
+                ls += sc[k][i];                                                                                    \
+            }                                                                                                      \
+        l_run = l_run * alpha + ls;                                                                                \
+        m_run = m_new;                                                                                             \
+        if (FIRST) {                                                                                               \
+            RESID_PARTIAL()                                                                                        \
+            if (append_wave) {                                                                                     \
+                int row_n = rstart + r_old;                                                                        \
+                row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;                                                  \
+                const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;              \
+                *(h2 *)(p.k_res_w + o) = new_k;                                                                    \
+                *(h2 *)(p.v_res_w + o) = new_v;                                                                    \
+            }                                                                                                      \
+            v4u *ld = (v4u *)(smem + kVBase);                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabv[i];        \
+            __syncthreads();                                                                                       \
+        }                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < kRing; ++k) {                                                        \
+            const int j = (PASS) * kRing + k;                                                                      \
+            if (HAS_CODES && j < n_mine) value_unit(ring[k].v, sc[k], vconst0, vconst1, O);                        \
+            if (HAS_CODES && (REFILL)) load_unit(p, b, hk, bh, UNIT_T(j + kRing), T_ld, lane, ring[k]);            \
+        }                                                                                                          \
     }
+
+    // group 0 (every wave, also one without units: it carries the V-codebook barrier); masked because it
+    // may be the last; refills only if more groups follow
+    GROUP(0, true, true, n_pass > 1)
+    // middle groups: full units, unconditional refills (counted waits, see the note above load_unit)
+    for (int pass = 1; pass + 1 < n_pass; ++pass) GROUP(pass, false, false, true)
+    // last group: masked, no refills
+    if (n_pass > 1) GROUP(n_pass - 1, true, false, false)
+#undef GROUP
+#undef RESID_PARTIAL
 #undef UNIT_T
     // residual groups beyond the LDS-staged ones (only when a split holds more than 32 window rows):
     // slow path, loads inside; each becomes a partial merged online into (m_late, l_late, olate)
@@ -554,8 +609,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     }
     MILLION_STAMP(p, 3);
     // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = rows_sum(l_run);
     __syncthreads();
     MILLION_STAMP(p, 4);
     const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
@@ -646,6 +700,18 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     MILLION_STAMP(p, 5);
     publish_and_merge(p, b, hk, split, part, scr, flag);
     MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
+}
+
+// Self-check of the row-swap reductions (tests/test_gpu_parity.py): one wave, in[64] -> max / sum over the
+// four 16-lane rows per column.
+__global__ void rows_reduce_check_kernel(const float *in, float *out_max, float *out_sum) {
+    const float x = in[threadIdx.x];
+    out_max[threadIdx.x] = rows_max(x);
+    out_sum[threadIdx.x] = rows_sum(x);
+}
+int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hipStream_t s) {
+    hipLaunchKernelGGL(rows_reduce_check_kernel, dim3(1), dim3(64), 0, s, in, out_max, out_sum);
+    return hipGetLastError() == hipSuccess ? MILLION_OK : MILLION_ERR_LAUNCH;
 }
 
 bool attn_mfma_shape_ok(const AttnParams &p) { return p.d == 128 && p.M == 64 && p.C == 256 && p.G <= kMaxG; }

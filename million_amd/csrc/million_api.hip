@@ -175,6 +175,9 @@ int million_version(void) { return MILLION_HIP_VERSION; }
 const char *million_last_error(void) { return g_err; }
 void million_set_force_generic(int on) { g_force_generic = on; }
 void million_debug_set_stamp_buffer(void *buf) { g_dbg = (unsigned long long *)buf; }
+int million_debug_rows_reduce(const float *in64, float *out_max64, float *out_sum64, million_stream_t stream) {
+    return launch_rows_reduce_check(in64, out_max64, out_sum64, (hipStream_t)stream);
+}
 
 size_t million_prepared_cents_bytes(int M, int C, int d_m) { return (size_t)2 * M * C * d_m * sizeof(f16); }
 

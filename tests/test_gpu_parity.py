@@ -352,3 +352,22 @@ def test_dynamic_cache_decode_sequence(env, oracle):
             vres = np.zeros((bs, nhk, 128, d), np.float16)
             kres[:, :, :r], vres[:, :, :r] = K[:, :, T:T + r], V[:, :, T:T + r]
             _check(out.cpu().numpy(), oracle.decode_attn(Q[i], kc, vc, ck, cv, kres, vres, r), f"dynamic step {i}")
+
+
+def test_rows_reduce_selfcheck(env):
+    """The kernel's VALU-only row reductions (v_permlane16_swap / v_permlane32_swap) against numpy: guards the
+    hipcc pitfall of passing one SSA value as both swap operands (see attn_mfma.hip)."""
+    torch, ops = env
+    from million_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal(64).astype(np.float32)
+    x[5], x[37], x[60] = 1000.0, -7.0, np.float32(-np.inf)
+    xd = torch.from_numpy(x).cuda()
+    om, osum = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    assert lib.million_debug_rows_reduce(xd.data_ptr(), om.data_ptr(), osum.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    xr = x.reshape(4, 16)
+    np.testing.assert_array_equal(om.cpu().numpy().reshape(4, 16), np.broadcast_to(xr.max(0), (4, 16)))
+    want = (xr[0] + xr[1]) + (xr[2] + xr[3])
+    np.testing.assert_array_equal(osum.cpu().numpy().reshape(4, 16), np.broadcast_to(want, (4, 16)))

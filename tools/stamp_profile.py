@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase timing of the fused decode-attention kernel from in-kernel realtime stamps
-(million_debug_set_stamp_buffer).  Shares = where a workgroup's wall time goes; not a benchmark."""
+(million_debug_set_stamp_buffer; lane 0 of wave 0 of every workgroup).  Shares = where a workgroup's
+wall time goes; not a benchmark."""
 import argparse
 import sys
 from pathlib import Path
@@ -48,37 +49,32 @@ for i in range(2 * args.layers):
     run(i)
 torch.cuda.synchronize()
 lib.million_debug_set_stamp_buffer(stamps.data_ptr())
-acc = []
+spans, last = [], None
 for i in range(args.layers):
     stamps.zero_()
     run(i)
     torch.cuda.synchronize()
     s = stamps.cpu().numpy().reshape(-1, 16)
     s = s[s[:, 0] != 0]
-    acc.append(s)
+    spans.append((s[:, 6].max() - s[:, 0].min()) / 100.0)
+    last = s
 lib.million_debug_set_stamp_buffer(None)
-names = ["prologue: loads issued, tables -> LDS, barrier", "residual-window partial (waves 0,1)",
-         "code units (MFMA loop)", "wave merge barrier", "wave merge compute", "publish (+ last-arriver merge)"]
-tot = []
-for s in acc:
-    t0 = s[:, 0].min()
-    tot.append(((s[:, 6].max() - t0) / 100.0, s.shape[0]))
-    rel = (s - t0) / 100.0      # us since the first workgroup started
-    d = np.diff(s[:, :7].astype(np.float64), axis=1) / 100.0
-print(f"workgroups {tot[-1][1]}; kernel span (first start -> last end) per launch [us]:", [round(t[0], 2) for t in tot])
-print("last launch: start skew of workgroups [us]: min %.2f max %.2f" % (rel[:, 0].min(), rel[:, 0].max()))
-for i, n in enumerate(names):
-    print(f"  phase {i} {n:45s} mean {d[:, i].mean():6.2f}  min {d[:, i].min():6.2f}  max {d[:, i].max():6.2f} us")
-print("  end of phase 5 rel. to first start: mean %.2f max %.2f us" % (rel[:, 6].mean(), rel[:, 6].max()))
-if s[:, 10].any():
-    la = s[s[:, 11] != 0]
-    print("  publish: stores+ticket %.2f us (mean, all WGs); last arrivers (%d): ticket->weights ready %.2f | ->out written %.2f us" % (
-        ((s[:, 10] - s[:, 5]) / 100.0).mean(), la.shape[0], ((la[:, 11] - la[:, 10]) / 100.0).mean(), ((la[:, 6] - la[:, 11]) / 100.0).mean()))
-if s[:, 7].any():
-    if s[:, 9].any():
-        print("  wave 0: start->all loads issued %.2f | residual partial (incl. wait for its rows) %.2f us" % (
-            ((s[:, 9] - s[:, 0]) / 100.0).mean(), ((s[:, 7] - s[:, 9]) / 100.0).mean()))
-    a = (s[:, 7] - s[:, 0]) / 100.0
-    b_ = (s[:, 8] - s[:, 7]) / 100.0
-    c = (s[:, 1] - s[:, 8]) / 100.0
-    print("  prologue detail: start->loads issued %.2f | issued->tables in LDS %.2f | ->barrier done %.2f us (means)" % (a.mean(), b_.mean(), c.mean()))
+# stamp ids in program order, and what ends at each
+order = [(0, "kernel start"), (7, "q + K codebook + code unit 0 requested"), (8, "K codebook written to LDS"),
+         (1, "barrier 1 (K codebook)"), (9, "rest requested: residual rows, units 1-3, V codebook"),
+         (2, "accumulators initialised"), (3, "all groups done (score pass, V-codebook barrier, value pass)"),
+         (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
+s = last
+t0 = s[:, 0].min()
+print(f"workgroups {s.shape[0]}; kernel span (first start -> last end) per launch [us]: {[round(float(x), 2) for x in spans]}")
+print("start skew of workgroups [us]: max %.2f" % ((s[:, 0].max() - t0) / 100.0))
+prev = 0
+for sid, name in order[1:]:
+    d = (s[:, sid] - s[:, prev]) / 100.0
+    print(f"  +{d.mean():6.2f} us (min {d.min():5.2f} max {d.max():5.2f})  -> {name}")
+    prev = sid
+la = s[s[:, 11] != 0]
+if la.shape[0]:
+    print("  last arrivers (%d): ticket -> weights ready %.2f | -> out written %.2f us" % (
+        la.shape[0], ((la[:, 11] - la[:, 10]) / 100.0).mean(), ((la[:, 6] - la[:, 11]) / 100.0).mean()))
+print("  end relative to first start: mean %.2f max %.2f us" % (((s[:, 6] - t0) / 100.0).mean(), ((s[:, 6] - t0) / 100.0).max()))
