@@ -1,0 +1,207 @@
+"""Self-contained Llama-shaped decoder for end-to-end decode timing (SURVEY.md 8f-2 "harness glue").
+
+The reference patches HF's LlamaSdpaAttention.forward (scripts/modeldb/models/modeling_llama.py:455-554
+attn_forward_custom_kernel, :345-453 baseline_forward) inside `model.generate`; the installed transformers
+no longer has that class, and no weights exist offline, so this is a plain-torch restatement of the decode
+step of a Llama block with random fp16 weights (the reference's `_synthetic` mode, main_pq.py:252-255,
+speedtest.py:31-33).  Everything outside attention (RMSNorm, q/k/v/o projections, RoPE, SwiGLU MLP,
+lm_head, greedy argmax) is torch / hipBLASLt — plumbing, identical for every attention backend:
+
+  * "hf_baseline"  — the reference's fp16 full-KV baseline recipe: DynamicCache-style torch.cat append,
+                     repeat_kv, scaled_dot_product_attention (modeling_llama.py:403-443);
+  * "static_fp16"  — the same attention on a preallocated cache, GQA without materialising repeat_kv
+                     (a stronger fp16 baseline, for the record);
+  * "pq"           — PagedPQCache.decoding_with_pages: flush-if-full + fused append + PQ attention (this repo).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class LlamaShape:
+    hidden: int = 4096
+    n_layers: int = 32
+    nh: int = 32
+    nh_k: int = 8
+    d: int = 128
+    inter: int = 14336
+    vocab: int = 128256
+    rope_theta: float = 500000.0
+    eps: float = 1e-5
+
+    @staticmethod
+    def llama31_8b():
+        return LlamaShape()
+
+    @staticmethod
+    def llama2_7b():
+        return LlamaShape(nh_k=32, inter=11008, vocab=32000, rope_theta=10000.0)
+
+
+def repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
+    """transformers.models.llama.modeling_llama.repeat_kv: (b, nh_k, T, d) -> (b, nh_k*n_rep, T, d), materialised."""
+    b, h, t, d = x.shape
+    if n_rep == 1:
+        return x
+    return x[:, :, None, :, :].expand(b, h, n_rep, t, d).reshape(b, h * n_rep, t, d)
+
+
+class HFBaselineCache:
+    """fp16 full-KV cache grown by torch.cat (HF DynamicCache.update), + repeat_kv + SDPA."""
+
+    def __init__(self, shape: LlamaShape, bs: int, ctx: int, device):
+        self.G = shape.nh // shape.nh_k
+        mk = lambda: torch.randn(bs, shape.nh_k, ctx, shape.d, device=device, dtype=torch.float16)
+        self.k = [mk() for _ in range(shape.n_layers)]
+        self.v = [mk() for _ in range(shape.n_layers)]
+
+    def attend(self, layer, q, k, v):
+        self.k[layer] = torch.cat([self.k[layer], k], dim=2)
+        self.v[layer] = torch.cat([self.v[layer], v], dim=2)
+        return F.scaled_dot_product_attention(q, repeat_kv(self.k[layer], self.G), repeat_kv(self.v[layer], self.G))
+
+
+class StaticFP16Cache:
+    """Preallocated fp16 cache; GQA handled by viewing the G query heads of a kv head as G query rows."""
+
+    def __init__(self, shape: LlamaShape, bs: int, ctx: int, max_new: int, device):
+        self.shape, self.T = shape, ctx
+        mk = lambda: torch.randn(bs, shape.nh_k, ctx + max_new, shape.d, device=device, dtype=torch.float16)
+        self.k = [mk() for _ in range(shape.n_layers)]
+        self.v = [mk() for _ in range(shape.n_layers)]
+
+    def attend(self, layer, q, k, v):
+        s = self.shape
+        T = self.T
+        self.k[layer][:, :, T:T + 1] = k
+        self.v[layer][:, :, T:T + 1] = v
+        bs = q.shape[0]
+        qg = q.view(bs, s.nh_k, s.nh // s.nh_k, s.d)
+        out = F.scaled_dot_product_attention(qg, self.k[layer][:, :, :T + 1], self.v[layer][:, :, :T + 1])
+        if layer == s.n_layers - 1:
+            self.T += 1
+        return out.view(bs, s.nh, 1, s.d)
+
+
+class PQBackend:
+    def __init__(self, shape: LlamaShape, bs: int, ctx: int, max_new: int, device, M=64):
+        from .pq_cache import PagedPQCache
+        ps, cap = 64, 128
+        T0 = ctx // ps * ps
+        self.cache = PagedPQCache(bs=bs, nh=shape.nh, num_key_value_heads=shape.nh_k, M=M, layer_num=shape.n_layers,
+                                  d=shape.d, page_size=ps, extended_residual_size=cap, max_tokens=T0 + max_new + 2 * cap,
+                                  device=device)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        self.cache.set_cent(torch.randn(M, 256, shape.d // M, generator=g).half().to(device),
+                            torch.randn(M, 256, shape.d // M, generator=g).half().to(device))
+        gd = torch.Generator(device=device).manual_seed(11)
+        for pool in (self.cache.key_page_pool, self.cache.value_page_pool):
+            pool.copy_(torch.randint(0, 256, pool.shape, dtype=torch.uint8, device=device, generator=gd))
+        L = shape.n_layers
+        self.cache.set_host_state(([T0] * L, [0] * L, [T0] * L, [0] * L))      # window empty after prefill
+        for l in range(L):
+            self.cache._sync_lengths(l)
+        self.use_dev_lengths = False
+
+    def attend(self, layer, q, k, v):
+        return self.cache.decoding_with_pages(q, k, v, layer, use_dev_lengths=self.use_dev_lengths)
+
+
+class LlamaShapeDecoder:
+    """Random-weight Llama decoder; `step(tokens, pos, backend)` runs one decode step and returns argmax ids."""
+
+    def __init__(self, shape: LlamaShape, device, seed=0):
+        self.s, self.device = shape, device
+        g = torch.Generator(device=device).manual_seed(seed)
+        h, s = shape.hidden, shape
+
+        def w(n_out, n_in):
+            return (torch.randn(n_out, n_in, generator=g, device=device, dtype=torch.float16) / math.sqrt(n_in))
+
+        self.embed = torch.randn(s.vocab, h, generator=g, device=device, dtype=torch.float16)
+        self.layers = []
+        for _ in range(s.n_layers):
+            self.layers.append(dict(wqkv=w((s.nh + 2 * s.nh_k) * s.d, h), wo=w(h, s.nh * s.d), wgu=w(2 * s.inter, h),
+                                    wd=w(h, s.inter), n1=torch.ones(h, device=device, dtype=torch.float16),
+                                    n2=torch.ones(h, device=device, dtype=torch.float16)))
+        self.norm = torch.ones(h, device=device, dtype=torch.float16)
+        self.lm_head = w(s.vocab, h)
+        inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.d, 2, device=device, dtype=torch.float32) / s.d))
+        self.inv_freq = inv
+
+    def _rms(self, x, w):
+        v = x.float()
+        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.s.eps)).half() * w
+
+    def _rope(self, x, pos):
+        # x (bs, heads, 1, d); HF rotate_half convention
+        ang = pos.float()[:, None] * self.inv_freq[None, :]            # (bs, d/2)
+        cos = torch.cat([ang.cos(), ang.cos()], -1)[:, None, None, :].half()
+        sin = torch.cat([ang.sin(), ang.sin()], -1)[:, None, None, :].half()
+        x1, x2 = x[..., : self.s.d // 2], x[..., self.s.d // 2:]
+        return x * cos + torch.cat([-x2, x1], -1) * sin
+
+    def step(self, tokens, pos, backend):
+        s = self.s
+        bs = tokens.shape[0]
+        x = self.embed[tokens]                                           # (bs, hidden)
+        for l, L in enumerate(self.layers):
+            hN = self._rms(x, L["n1"])
+            qkv = F.linear(hN, L["wqkv"])
+            q = qkv[:, : s.nh * s.d].view(bs, s.nh, 1, s.d)
+            k = qkv[:, s.nh * s.d: (s.nh + s.nh_k) * s.d].view(bs, s.nh_k, 1, s.d)
+            v = qkv[:, (s.nh + s.nh_k) * s.d:].view(bs, s.nh_k, 1, s.d)
+            q, k = self._rope(q, pos), self._rope(k, pos)
+            a = backend.attend(l, q.contiguous(), k.contiguous(), v.contiguous())
+            x = x + F.linear(a.reshape(bs, s.nh * s.d), L["wo"])
+            hN = self._rms(x, L["n2"])
+            gu = F.linear(hN, L["wgu"])
+            x = x + F.linear(F.silu(gu[:, : s.inter]) * gu[:, s.inter:], L["wd"])
+        self.last_logits = F.linear(self._rms(x, self.norm), self.lm_head)
+        return self.last_logits.argmax(-1)
+
+
+class GraphedPQDecoder:
+    """The whole decode step (all layers + lm_head + argmax + token feedback) captured in two hipGraphs —
+    a plain step and a step whose layers flush a page first; lengths live on the device
+    (PagedPQCache.lengths), so a replay touches no host state."""
+
+    def __init__(self, model: LlamaShapeDecoder, backend: PQBackend, tokens: torch.Tensor, pos: torch.Tensor):
+        self.model, self.be, self.tokens, self.pos = model, backend, tokens, pos
+        cache, L, cap = backend.cache, model.s.n_layers, backend.cache.extended_residual_size
+        backend.use_dev_lengths = True
+        st = cache.host_state()
+        dl_backup = [t.clone() for t in cache.lengths]
+        tok0, pos0 = tokens.clone(), pos.clone()
+        # the warm-up step below really runs: keep the window rows it overwrites
+        self._eager_step()                     # allocates workspaces, warms hipBLASLt heuristics
+        torch.cuda.synchronize()
+        self.graphs = {}
+        for name, r_cap in (("plain", st[1][0] if st[1][0] < cap else 0), ("flush", cap)):
+            cache.set_host_state((st[0], [r_cap] * L, st[2], st[3]))
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._eager_step()
+            self.graphs[name] = gr
+        cache.set_host_state(st)
+        for t, b in zip(cache.lengths, dl_backup):
+            t.copy_(b)
+        tokens.copy_(tok0)
+        pos.copy_(pos0)
+        torch.cuda.synchronize()
+
+    def _eager_step(self):
+        nxt = self.model.step(self.tokens, self.pos, self.be)
+        self.tokens.copy_(nxt)
+        self.pos.add_(1)
+
+    def step(self):
+        cache = self.be.cache
+        self.graphs["flush" if cache.next_step_flushes() else "plain"].replay()
+        cache.note_replayed_step()
+        return self.tokens

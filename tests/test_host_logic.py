@@ -98,3 +98,30 @@ def test_multirank_timing_gloo():
     assert e0 == e1 and e0 >= 5 * 0.03 * 0.9            # both ranks report rank 1's (max) time
     assert v0 == v1 == pytest.approx(10 / e0)
     assert s0 + s1 == list(range(5))
+
+
+def test_harness_fp16_backends_agree_cpu():
+    """million_amd/harness.py: the HF-recipe baseline (torch.cat + repeat_kv + SDPA, modeling_llama.py:403-443)
+    and the preallocated GQA-view baseline are the same attention; tiny shape, CPU, fp32 weights."""
+    from million_amd import harness as H
+    shape = H.LlamaShape(hidden=64, n_layers=2, nh=4, nh_k=2, d=16, inter=96, vocab=50)
+    torch.manual_seed(0)
+    model = H.LlamaShapeDecoder(shape, torch.device("cpu"))
+    ctx, bs = 24, 2
+    hf = H.HFBaselineCache(shape, bs, ctx, torch.device("cpu"))
+    st = H.StaticFP16Cache(shape, bs, ctx, 8, torch.device("cpu"))
+    for l in range(shape.n_layers):
+        st.k[l][:, :, :ctx] = hf.k[l]
+        st.v[l][:, :, :ctx] = hf.v[l]
+    tok_a = torch.zeros(bs, dtype=torch.long)
+    tok_b = tok_a.clone()
+    pos = torch.full((bs,), ctx, dtype=torch.long)
+    for i in range(4):
+        tok_a = model.step(tok_a, pos + i, hf)
+        tok_b = model.step(tok_b, pos + i, st)
+        assert torch.equal(tok_a, tok_b)
+    assert hf.k[0].shape[2] == ctx + 4 and st.T == ctx + 4
+    # repeat_kv layout: head h of the output is kv head h // G
+    x = torch.arange(2 * 2 * 3 * 1, dtype=torch.float32).view(2, 2, 3, 1)
+    r = H.repeat_kv(x, 2)
+    assert r.shape == (2, 4, 3, 1) and torch.equal(r[:, 1], x[:, 0]) and torch.equal(r[:, 2], x[:, 1])
