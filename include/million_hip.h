@@ -183,7 +183,7 @@ int million_residual_append(const void *k_new, const void *v_new, void *k_resid,
 int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int resid_cap, million_stream_t stream);
 
 /* Diagnostics only: when `buf` is non-NULL the decode-attention kernels store up to 16 x uint64 realtime-counter
- * stamps (100 MHz) per workgroup at their phase boundaries into buf (grid_size * 16 entries).  NULL = off. */
+ * stamps (100 MHz) per wave at their phase boundaries into buf (grid_size * 8 waves * 32 slots entries).  NULL = off. */
 void million_debug_set_stamp_buffer(void *buf);
 /* Diagnostics only: runs the kernel's row-swap reductions on one wave: out_max[l] / out_sum[l] = max / sum of
  * in[l % 16 + 16*k], k = 0..3 (device pointers to 64 floats each). */

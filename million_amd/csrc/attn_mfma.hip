@@ -39,11 +39,10 @@ static_assert(true, "");
 constexpr int kRing = 4;                     // 32-token units in flight per wave (16 VGPRs each)
 constexpr int kTabBytes = 64 * 1024;         // one codebook image (M*C*dm*2)
 constexpr int kVBase = kTabBytes;            // V col image behind the K row image
-constexpr int kPartOff = 2 * kTabBytes;      // [128K,136K): final partial, flag, residual (m, l)
-constexpr int kResWaves = 2;                 // residual groups (16 rows each) staged in LDS per workgroup
-constexpr int kResOut = kPartOff + 8192;     // [136K,144K): per group O_res[G][128] fp32
-constexpr int kResML = kPartOff + 6144;      // per group m[8], l[8]
-constexpr int kLdsBytes = kResOut + kResWaves * 4096;  // 144 KiB
+constexpr int kPartOff = 2 * kTabBytes;      // [128K,136K): final partial, flag
+constexpr int kStampOff = kPartOff + 8192;   // [136K,138K): diagnostic stamps (only touched when a stamp buffer is set)
+constexpr int kLdsBytes = kStampOff + kStampWaves * kStampSlots * 8;  // 138 KiB
+constexpr int kResRows = 16;                 // residual-window rows per wave (one MFMA tile): 8 waves x 16 = 128 rows per split
 
 struct UnitCodes {
     v4u k[2];   // K code bytes: group g2 (16 tokens), lane (q, c): token c, bytes [16q, 16q+16)
@@ -169,13 +168,12 @@ __device__ __forceinline__ void load_pids4(const AttnParams &p, int bh, const in
     }
 }
 
-// Request the 4 x 16-byte loads of one 32-token unit (see UnitCodes).  t_unit: multiple of 32, < T.
-__device__ __forceinline__ void load_unit_pid(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
-                                              int lane, UnitCodes &u) {
-    const int q4 = lane >> 4, c16 = lane & 15, h2i = lane >> 5, c32 = lane & 31;
-    const int page = t_unit >> p.ps_shift;                           // a unit never straddles a page
-    const int page0 = page << p.ps_shift;
-    const int inpage = t_unit - page0;
+// Request the 16-byte loads of one 32-token unit (see UnitCodes): two for the K bytes, two for the V bytes.
+// t_unit: multiple of 32, < T.
+__device__ __forceinline__ void load_unit_k(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
+                                            int lane, UnitCodes &u) {
+    const int q4 = lane >> 4, c16 = lane & 15;
+    const int page0 = (t_unit >> p.ps_shift) << p.ps_shift;          // a unit never straddles a page
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
         int tok = t_unit + 16 * g2 + c16;
@@ -185,38 +183,58 @@ __device__ __forceinline__ void load_unit_pid(const AttnParams &p, int b, int hk
             : p.k_codes + b * p.k_sb + hk * p.k_sh + ((long long)tok << 6) + 16 * q4;
         u.k[g2] = *(const v4u *)src;
     }
+}
+__device__ __forceinline__ void load_unit_v(const AttnParams &p, const PidPair &pid, int t_unit, int lane, UnitCodes &u) {
+    const int h2i = lane >> 5, c32 = lane & 31;
+    const int inpage = t_unit - ((t_unit >> p.ps_shift) << p.ps_shift);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const uint8_t *src = p.v_codes + (((pid.v << 6) + 32 * n + c32) << p.ps_shift) + inpage + 16 * h2i;
         u.v[n] = *(const v4u *)src;
     }
 }
+__device__ __forceinline__ void load_unit_pid(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
+                                              int lane, UnitCodes &u) {
+    load_unit_k(p, b, hk, pid, t_unit, T, lane, u);
+    load_unit_v(p, pid, t_unit, lane, u);
+}
 __device__ __forceinline__ void load_unit(const AttnParams &p, int b, int hk, int bh, int t_unit, int T,
                                           int lane, UnitCodes &u) {
     load_unit_pid(p, b, hk, load_pids(p, bh, t_unit >> p.ps_shift), t_unit, T, lane, u);
 }
 
+// Four centroid gathers of one score step: code bytes w -> A operand words (subspaces 4s..4s+3 of this lane's quarter).
+__device__ __forceinline__ void k_gather(unsigned w, unsigned base, unsigned (&a)[4]) {
+    a[0] = lds32(base + 0 * 1024 + ((w & 0xffu) << 2));
+    a[1] = lds32(base + 1 * 1024 + (((w >> 8) & 0xffu) << 2));
+    a[2] = lds32(base + 2 * 1024 + (((w >> 16) & 0xffu) << 2));
+    a[3] = lds32(base + 3 * 1024 + ((w >> 24) << 2));
+}
+
 // Scores of one 32-token unit (MFMA 16x16x32): sc[g2*4 + rho] = scaled score (exp2 domain) of token
 // 16*g2 + 4*q' + rho for the head of this lane's column (lane & 15); -inf beyond the split's last token.
+// 8 steps (g2, s) of 4 gathers + 1 MFMA; the gathers run kDepth steps ahead of the MFMAs so that the LDS
+// queue of this wave never drains (two waves per SIMD do not hide an LDS round trip per step).
 template <bool MASK>
 __device__ __forceinline__ void score_unit(const v4u (&kc)[2], const v8f16 (&qb)[4], int t_unit, int t_end,
                                            float scale_log2e, int lane, unsigned kbase, float (&sc)[8]) {
     const int q4 = lane >> 4;
+    constexpr int kDepth = 3;
+    unsigned a[8][4];
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
-        v4f32 D = {0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < kDepth; ++st) k_gather(kc[st >> 2][st & 3], kbase + (st & 3) * 4096, a[st]);
+    v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const unsigned w = kc[g2][s];
-            const unsigned a0 = lds32(kbase + (4 * s + 0) * 1024 + ((w & 0xffu) << 2));
-            const unsigned a1 = lds32(kbase + (4 * s + 1) * 1024 + (((w >> 8) & 0xffu) << 2));
-            const unsigned a2 = lds32(kbase + (4 * s + 2) * 1024 + (((w >> 16) & 0xffu) << 2));
-            const unsigned a3 = lds32(kbase + (4 * s + 3) * 1024 + ((w >> 24) << 2));
-            D = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(a0, a1, a2, a3), qb[s], D, 0, 0, 0);
-        }
+    for (int st = 0; st < 8; ++st) {
+        if (st + kDepth < 8) k_gather(kc[(st + kDepth) >> 2][(st + kDepth) & 3], kbase + ((st + kDepth) & 3) * 4096, a[st + kDepth]);
+        D[st >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(a[st][0], a[st][1], a[st][2], a[st][3]), qb[st & 3],
+                                                            D[st >> 2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
         for (int rho = 0; rho < 4; ++rho) {
-            const float v = D[rho] * scale_log2e;
+            const float v = D[g2][rho] * scale_log2e;
             if (MASK) {
                 const int tok = t_unit + 16 * g2 + 4 * q4 + rho;
                 sc[g2 * 4 + rho] = tok < t_end ? v : -INFINITY;
@@ -224,7 +242,6 @@ __device__ __forceinline__ void score_unit(const v4u (&kc)[2], const v8f16 (&qb)
                 sc[g2 * 4 + rho] = v;
             }
         }
-    }
 }
 
 // Values of one 32-token unit: O[n][kk] (rows = heads, cols = subspaces 32n..32n+31) += P (heads x tokens) * Vhat.
@@ -255,76 +272,110 @@ __device__ __forceinline__ void value_unit(const v4u (&vc)[2], const float (&pr)
             P[s][2 + i] = y[1];
         }
     }
+    // 4 steps (n, s) of 8 gathers + 2 MFMAs; the gathers of the next step are issued before this step's MFMAs
+    unsigned e[4][8];
+#define V_GATHER(ST)                                                                                               \
+    {                                                                                                              \
+        const unsigned vconst = ((ST) >> 1) ? vconst1 : vconst0;                                                   \
+        const unsigned w0 = vc[(ST) >> 1][2 * ((ST) & 1)], w1 = vc[(ST) >> 1][2 * ((ST) & 1) + 1];                 \
+        e[ST][0] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020400u));                                          \
+        e[ST][1] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020500u));                                          \
+        e[ST][2] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020600u));                                          \
+        e[ST][3] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020700u));                                          \
+        e[ST][4] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020400u));                                          \
+        e[ST][5] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020500u));                                          \
+        e[ST][6] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020600u));                                          \
+        e[ST][7] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020700u));                                          \
+    }
+    V_GATHER(0)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const unsigned vconst = n ? vconst1 : vconst0;
+    for (int st = 0; st < 4; ++st) {
+        if (st == 0) V_GATHER(1)
+        if (st == 1) V_GATHER(2)
+        if (st == 2) V_GATHER(3)
+        const int n = st >> 1, sidx = st & 1;
+        const v8f16 B0 = as_v8f16(__builtin_amdgcn_perm(e[st][1], e[st][0], 0x05040100u), __builtin_amdgcn_perm(e[st][3], e[st][2], 0x05040100u),
+                                  __builtin_amdgcn_perm(e[st][5], e[st][4], 0x05040100u), __builtin_amdgcn_perm(e[st][7], e[st][6], 0x05040100u));
+        const v8f16 B1 = as_v8f16(__builtin_amdgcn_perm(e[st][1], e[st][0], 0x07060302u), __builtin_amdgcn_perm(e[st][3], e[st][2], 0x07060302u),
+                                  __builtin_amdgcn_perm(e[st][5], e[st][4], 0x07060302u), __builtin_amdgcn_perm(e[st][7], e[st][6], 0x07060302u));
+        const v8f16 A = as_v8f16(P[sidx][0], P[sidx][1], P[sidx][2], P[sidx][3]);
+        O[n][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B0, O[n][0], 0, 0, 0);
+        O[n][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B1, O[n][1], 0, 0, 0);
+    }
+#undef V_GATHER
+}
+
+// ---- residual window -------------------------------------------------------------------------------
+// The window rows j = split, split + nsplit, ... < r of a split are dealt to its waves round-robin: wave w
+// owns list entries idx = w + 8*i, i < kResRows, as ONE 16-row MFMA tile that rides along with the code
+// units of the first group: scores with A = the fp16 K rows themselves, values with B = the fp16 V rows
+// (k = 16 rows, cols = 32 subspaces; even / odd dims by v_perm like the looked-up centroids).  Rows past the
+// list re-read the wave's first row and are masked to -inf.
+struct ResTile {
+    v4u k[4];          // lane (q4, c16): row c16 of the tile, dims 32*q4 + 8*s .. + 8
+    unsigned v[2][8];  // lane (h, c32): rows 8*h + j, dims (2m, 2m+1) of subspace m = 32*n + c32
+};
+
+// Row pointer of list entry idx (clamped to the wave's first entry, which exists when the tile is used).
+__device__ __forceinline__ long long res_row_off(const AttnParams &p, int idx, int wave, int rcnt, int split, int rstart,
+                                                 int r_old, bool &is_new) {
+    const int idc = idx < rcnt ? idx : wave;
+    const int j = split + idc * p.nsplit;
+    int row = rstart + j;
+    row = row >= p.rcap ? row - p.rcap : row;          // rstart, j < rcap: one wrap at most
+    is_new = p.k_new && j == r_old;                    // fused append: the new token is window row r_old
+    return (long long)row * 128;
+}
+
+__device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const f16 *kr, const f16 *vr, int wave, int rcnt,
+                                              int split, int rstart, int r_old, int lane, ResTile &t) {
+    const int q4 = lane >> 4, c16 = lane & 15, h = lane >> 5, c32 = lane & 31;
+    {
+        bool is_new;
+        const long long off = res_row_off(p, wave + kNW * c16, wave, rcnt, split, rstart, r_old, is_new);
+        const f16 *kp = (is_new ? p.k_new + (long long)bh * 128 : kr + off) + 32 * q4;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const unsigned w0 = vc[n][2 * s], w1 = vc[n][2 * s + 1];
-            const unsigned e0 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020400u));
-            const unsigned e1 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020500u));
-            const unsigned e2 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020600u));
-            const unsigned e3 = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020700u));
-            const unsigned e4 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020400u));
-            const unsigned e5 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020500u));
-            const unsigned e6 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020600u));
-            const unsigned e7 = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020700u));
-            const v8f16 B0 = as_v8f16(__builtin_amdgcn_perm(e1, e0, 0x05040100u), __builtin_amdgcn_perm(e3, e2, 0x05040100u),
-                                      __builtin_amdgcn_perm(e5, e4, 0x05040100u), __builtin_amdgcn_perm(e7, e6, 0x05040100u));
-            const v8f16 B1 = as_v8f16(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u),
-                                      __builtin_amdgcn_perm(e5, e4, 0x07060302u), __builtin_amdgcn_perm(e7, e6, 0x07060302u));
-            const v8f16 A = as_v8f16(P[s][0], P[s][1], P[s][2], P[s][3]);
-            O[n][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B0, O[n][0], 0, 0, 0);
-            O[n][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B1, O[n][1], 0, 0, 0);
-        }
+        for (int s = 0; s < 4; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bool is_new;
+        const long long off = res_row_off(p, wave + kNW * (8 * h + j), wave, rcnt, split, rstart, r_old, is_new);
+        const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 2 * c32;
+        t.v[0][j] = *(const unsigned *)vp;
+        t.v[1][j] = *(const unsigned *)(vp + 64);
     }
 }
 
-// One group of <= 16 residual-window rows as an independent softmax partial (m, l, O_res): kraw = this
-// lane's K row slice (A operand of the score MFMA, lane (q4, row c16): dims 32*q4 + 8*s ..), vrow[i] = dims
-// (2*lane, 2*lane+1) of the i-th row's V.  nvalid = rows of the group that exist.  On return lane g < G
-// holds (m, l) of head g, ores[g] = sum_i p[g][i] * V[i][2*lane .. 2*lane+1].
-__device__ __forceinline__ void resid_group(const v4u (&kraw)[4], const h2 (&vrow)[16], int nvalid,
-                                            const v8f16 (&qb)[4], float scale_log2e, int G, int lane,
-                                            float &m_out, float &l_out, float (&ores)[kMaxG][2]) {
+// scores of the tile: sc[rho] = row 4*q' + rho for the head of this lane's column
+__device__ __forceinline__ void score_res_tile(const ResTile &t, const v8f16 (&qb)[4], float scale_log2e, int wave, int rcnt,
+                                               int lane, float (&sc)[4]) {
     const int q4 = lane >> 4;
     v4f32 D = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        D = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, kraw[s]), qb[s], D, 0, 0, 0);
-    float sc[4];
-    float mx = -INFINITY;
+        D = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, t.k[s]), qb[s], D, 0, 0, 0);
 #pragma unroll
-    for (int rho = 0; rho < 4; ++rho) {
-        sc[rho] = (4 * q4 + rho) < nvalid ? D[rho] * scale_log2e : -INFINITY;
-        mx = fmaxf(mx, sc[rho]);
-    }
-    mx = rows_max(mx);
-    const float m_safe = mx > -INFINITY ? mx : 0.f;
-    float ls = 0.f;
+    for (int rho = 0; rho < 4; ++rho)
+        sc[rho] = (wave + kNW * (4 * q4 + rho)) < rcnt ? D[rho] * scale_log2e : -INFINITY;
+}
+
+// O += P (heads x 16 rows) * V rows.  pr[rho] = probability of row 4*q' + rho for the head of this lane's column.
+__device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&pr)[4], v16f32 (&O)[2][2]) {
+    h2 t0 = {(f16)pr[0], (f16)pr[1]}, t1 = {(f16)pr[2], (f16)pr[3]};
+    const v2u y0 = swap16_self(__builtin_bit_cast(unsigned, t0));     // [0]: rows 2h of the score layout, [1]: rows 2h + 1
+    const v2u y1 = swap16_self(__builtin_bit_cast(unsigned, t1));
+    const unsigned y00 = y0[0], y01 = y0[1], y10 = y1[0], y11 = y1[1];
+    const v8f16 A = as_v8f16(y00, y10, y01, y11);                     // rows 8h + (0,1), (2,3), (4,5), (6,7)
 #pragma unroll
-    for (int rho = 0; rho < 4; ++rho) {
-        sc[rho] = fast_exp2(sc[rho] - m_safe);
-        ls += sc[rho];
-    }
-    ls = rows_sum(ls);
-    m_out = mx;
-    l_out = ls;
-#pragma unroll
-    for (int g = 0; g < kMaxG; ++g) ores[g][0] = ores[g][1] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (i >= nvalid) break;                 // wave-uniform: typically <= 4 rows per split
-        const float v0 = (float)vrow[i][0], v1 = (float)vrow[i][1];
-#pragma unroll
-        for (int g = 0; g < kMaxG; ++g)
-            if (g < G) {
-                // p of (row i, head g) sits in lane 16*(i/4) + g, register i%4: v_readlane -> SGPR operand
-                const float pg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                    __builtin_bit_cast(int, sc[i & 3]), (i >> 2) * 16 + g));
-                ores[g][0] = fmaf(pg, v0, ores[g][0]);
-                ores[g][1] = fmaf(pg, v1, ores[g][1]);
-            }
+    for (int n = 0; n < 2; ++n) {
+        const unsigned(&e)[8] = t.v[n];
+        const v8f16 B0 = as_v8f16(__builtin_amdgcn_perm(e[1], e[0], 0x05040100u), __builtin_amdgcn_perm(e[3], e[2], 0x05040100u),
+                                  __builtin_amdgcn_perm(e[5], e[4], 0x05040100u), __builtin_amdgcn_perm(e[7], e[6], 0x05040100u));
+        const v8f16 B1 = as_v8f16(__builtin_amdgcn_perm(e[1], e[0], 0x07060302u), __builtin_amdgcn_perm(e[3], e[2], 0x07060302u),
+                                  __builtin_amdgcn_perm(e[5], e[4], 0x07060302u), __builtin_amdgcn_perm(e[7], e[6], 0x07060302u));
+        O[n][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B0, O[n][0], 0, 0, 0);
+        O[n][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B1, O[n][1], 0, 0, 0);
     }
 }
 
@@ -338,16 +389,24 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     const int bh = blockIdx.y;
     const int b = bh / p.nh_k, hk = bh % p.nh_k;
     const int G = p.G;
-    // ---- lengths: device-resident (graph replay) -> one scalar load, issued now and waited for after the
-    //      codebook and q loads (which need no length) have been issued ----
     typedef int v4i __attribute__((ext_vector_type(4)));
     v4i dl = {p.T, p.r, p.rstart, 0};
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    MILLION_STAMP(p, 0);
+    // Diagnostic stamps go to LDS (lane 0 of each wave) and are copied out at the very end: a global store
+    // per stamp would put a vmcnt(0) into the phases being timed.
+    const bool dbg_on = p.dbg != nullptr;
+#define STAMP(i)                                                                                                   \
+    do {                                                                                                           \
+        if (dbg_on && lane == 0)                                                                                   \
+            *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(                            \
+                kStampOff + (wave * kStampSlots + (i)) * 8) = __builtin_amdgcn_s_memrealtime();                    \
+    } while (0)
+    if (dbg_on && lane < kStampSlots)
+        *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8) = 0ull;
+    STAMP(0);
     const int q4 = lane >> 4, c16 = lane & 15;
 
-    // B operand of the score MFMA: the query heads (cols), K = 32 dims per step.  Oldest loads of the
-    // wave: the residual partial below needs them before the codebooks are here.
+    // B operand of the score MFMA: the query heads (cols), K = 32 dims per step.
     v8f16 qb[4];
     {
         const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
@@ -368,8 +427,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     }
     // ---- K codebook (8 x 16 B per thread): requested before anything that depends on a length.  Every
     //      workgroup needs the same 64 KiB at the same time: each starts at its own chunk so that the CUs
-    //      do not walk the L2 channels in lockstep.  The V codebook is requested AFTER the code ring: the
-    //      score pass needs only K, so V may land behind the first codes. ----
+    //      do not walk the L2 channels in lockstep. ----
     v4u tabk[8];
     const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
     {
@@ -377,7 +435,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
     }
-    if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4), after q and the tables have been requested
+    if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4), after q and the table have been requested
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
     int T = dl[0] < p.T ? dl[0] : p.T;     // the host value is the bound the grid was sized for
     const int r_old = dl[1], rstart = dl[2];
@@ -395,21 +453,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     const int t_last = (T_ld - 1) & ~31;
 #define UNIT_T(j) ((j) < n_mine ? t_begin + 32 * (wave + (j) * kNW) : t_last)
 
-    // ---- residual window rows of this split: j = split, split + nsplit, ... < r; 16 rows per group.
-    //      Groups 0..kResWaves-1 (all of them unless a split holds > 32 window rows) are requested by waves
-    //      0..kResWaves-1 before everything else (OLDER loads never make a later counted wait over-wait),
-    //      parked in LDS next to the tables, and turned into their own softmax partial right after the
-    //      barrier, in the shadow of the code loads.  Later groups take the slow path at the end. ----
+    // ---- residual window rows of this split (list j = split, split + nsplit, ... < r), dealt to the waves
+    //      round-robin; this wave's tile is requested BEFORE the code bytes: the counted wait in front of the
+    //      K-codebook store then covers these few L2-resident rows, not the HBM-bound code loads behind them ----
     const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
-    const int rgroups = (rcnt + 15) >> 4;
+    const bool has_res = wave < rcnt;                  // wave-uniform
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
-    const bool res_wave = wave < kResWaves && wave < rgroups;      // wave-uniform
+    ResTile rt;
+    if (has_res) load_res_tile(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
 
-    // ---- the first code unit of this wave, then the K codebook goes to LDS.  Only these 16 loads (q, K
-    //      codebook, unit 0) are issued before the first barrier: the CU's load path takes a few microseconds
-    //      to accept everything this workgroup requests (64 B/clk), and a wave cannot write its share of the
-    //      codebook while it is still stuck issuing loads. ----
+    // ---- the K bytes of the whole ring, then the K codebook goes to LDS ----
     UnitCodes ring[kRing];
     PidPair pid4[kRing];
     if (HAS_CODES) {
@@ -417,50 +471,40 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #pragma unroll
         for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
         load_pids4(p, bh, pg, pid4);        // one scalar round trip, after q and the K codebook have been requested
-        load_unit_pid(p, b, hk, pid4[0], UNIT_T(0), T_ld, lane, ring[0]);
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) load_unit_k(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
     }
-    MILLION_STAMP(p, 7);
+    STAMP(7);
     {
         v4u *ld = (v4u *)smem;
 #pragma unroll
         for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabk[i];
     }
-    MILLION_STAMP(p, 8);
-    __syncthreads();     // no LDS-DMA in flight: lgkmcnt(0) + s_barrier, unit 0 stays in flight
-    MILLION_STAMP(p, 1);
+    STAMP(8);
+    __syncthreads();     // no LDS-DMA in flight: lgkmcnt(0) + s_barrier, the code bytes stay in flight
+    STAMP(1);
 
-    // ---- everything else is requested now and lands while the first scores are computed: the residual rows
-    //      of this wave's group, code units 1..3, the V codebook ----
-    v4u rk[4];
-    h2 rv[16];
-    if (res_wave) {
-        const int i_lane = wave * 16 + c16;
-        const int j_lane = split + (i_lane < rcnt ? i_lane : 0) * p.nsplit;
-        int row_l = rstart + j_lane;
-        row_l = row_l >= p.rcap ? row_l - p.rcap : row_l;      // rstart, j < rcap: one wrap at most
-        const f16 *kp = (p.k_new && j_lane == r_old ? p.k_new + (long long)bh * 128 : kr + (long long)row_l * 128) + 32 * q4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) rk[s] = *(const v4u *)(kp + 8 * s);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ii = wave * 16 + i;
-            const int j = split + (ii < rcnt ? ii : 0) * p.nsplit;        // wave-uniform
-            int row_i = rstart + j;
-            row_i = row_i >= p.rcap ? row_i - p.rcap : row_i;
-            rv[i] = *(const h2 *)((p.v_new && j == r_old ? p.v_new + (long long)bh * 128 : vr + (long long)row_i * 128) + 2 * lane);
-        }
-    }
-    if (HAS_CODES) {
-#pragma unroll
-        for (int k = 1; k < kRing; ++k) load_unit_pid(p, b, hk, pid4[k], UNIT_T(k), T_ld, lane, ring[k]);
-    }
+    // ---- everything else is requested BETWEEN the score units of the first group (the K bytes and the K
+    //      codebook are there; a wave that first issued all its remaining loads would sit in a blocked issue
+    //      sequence while the LDS pipe idles): after unit 0 the V bytes of units 0-1, after unit 1 those of
+    //      units 2-3, after unit 2 the V codebook ----
     v4u tabv[8];
-    {
-        const v4u *vs = (const v4u *)p.v_tab_col;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tabv[i] = vs[((i + rot) & 7) * (kNW * 64) + tid];
+#define ISSUE_AFTER_UNIT(K)                                                                                        \
+    if ((K) == 0) {                                                                                                \
+        if (HAS_CODES) {                                                                                           \
+            _Pragma("unroll") for (int k2 = 0; k2 < kRing / 2; ++k2)                                               \
+                load_unit_v(p, pid4[k2], UNIT_T(k2), lane, ring[k2]);                                              \
+        }                                                                                                          \
+    } else if ((K) == 1) {                                                                                         \
+        if (HAS_CODES) {                                                                                           \
+            _Pragma("unroll") for (int k2 = kRing / 2; k2 < kRing; ++k2)                                           \
+                load_unit_v(p, pid4[k2], UNIT_T(k2), lane, ring[k2]);                                              \
+        }                                                                                                          \
+    } else if ((K) == 2) {                                                                                         \
+        const v4u *vs = (const v4u *)p.v_tab_col;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) tabv[i] = vs[((i + rot) & 7) * (kNW * 64) + tid];            \
     }
-    MILLION_STAMP(p, 9);
+
     float m_run = -INFINITY, l_run = 0.f;
     v16f32 O[2][2];
 #pragma unroll
@@ -469,41 +513,18 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
-    MILLION_STAMP(p, 2);
-
-    // this wave's residual group -> its own softmax partial (m, l, O_res) in LDS; runs between the score pass
-    // and the V-codebook barrier of the first group, when its rows have long arrived
-#define RESID_PARTIAL()                                                                                            \
-    if (res_wave) {                                                                                                \
-        /* opaque use: keeps hipcc from hoisting the fp16->fp32 conversions (and with them the wait for */        \
-        /* these rows) above the loads issued after them */                                                       \
-        asm volatile("" : "+v"(rk[0]), "+v"(rk[1]), "+v"(rk[2]), "+v"(rk[3]), "+v"(rv[0]), "+v"(rv[1]),          \
-                          "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),          \
-                          "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]),      \
-                          "+v"(rv[14]), "+v"(rv[15]));                                                             \
-        const int nv = rcnt - wave * 16;                                                                           \
-        float mr, lr, ores[kMaxG][2];                                                                              \
-        resid_group(rk, rv, nv < 16 ? nv : 16, qb, p.scale_log2e, G, lane, mr, lr, ores);                          \
-        float *ro = (float *)(smem + kResOut + wave * 4096);                                                       \
-        _Pragma("unroll") for (int g = 0; g < kMaxG; ++g)                                                          \
-            if (g < G) *(float2 *)(ro + g * 128 + 2 * lane) = float2{ores[g][0], ores[g][1]};                      \
-        if (lane < G) {                                                                                            \
-            float *ml = (float *)(smem + kResML) + wave * 16;                                                      \
-            ml[lane] = mr;                                                                                         \
-            ml[8 + lane] = lr;                                                                                     \
-        }                                                                                                          \
-    }
+    STAMP(2);
 
     const unsigned kbase = (unsigned)q4 * 16u * 1024u;                 // K row image: m = 16*q4 + ...
     const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);        // m = c
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);  // m = 32 + c
 
     // ---- groups of kRing units: SCORE pass for the whole group (K codebook only), one softmax update per
-    //      group, then the VALUE pass.  The V codebook goes to LDS between the two passes of the first group,
-    //      so the first scores are computed while it is still arriving. ----
+    //      group, then the VALUE pass.  The first group also carries this wave's residual tile, and the V
+    //      codebook goes to LDS between its two passes, so the first scores are computed while V is arriving. ----
 #define GROUP(PASS, MASKV, FIRST, REFILL)                                                                          \
     {                                                                                                              \
-        float sc[kRing][8];                                                                                        \
+        float sc[kRing][8], scr[4];                                                                                \
         _Pragma("unroll") for (int k = 0; k < kRing; ++k) {                                                        \
             const int j = (PASS) * kRing + k;                                                                      \
             if (HAS_CODES && j < n_mine)                                                                           \
@@ -511,8 +532,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
                                   kbase, sc[k]);                                                                   \
             else                                                                                                   \
                 _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[k][i] = -INFINITY;                                \
+            if (FIRST) {                                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                STAMP(16 + 2 * k);                                                                                 \
+                ISSUE_AFTER_UNIT(k)                                                                                \
+                STAMP(17 + 2 * k);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }                                                                                                      \
         }                                                                                                          \
-        float mx = sc[0][0];                                                                                       \
+        if ((FIRST) && has_res) score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);                      \
+        else _Pragma("unroll") for (int i = 0; i < 4; ++i) scr[i] = -INFINITY;                                     \
+        float mx = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));                                            \
         _Pragma("unroll") for (int k = 0; k < kRing; ++k)                                                          \
             _Pragma("unroll") for (int i = 0; i < 8; ++i) mx = fmaxf(mx, sc[k][i]);                                \
         mx = rows_max(mx);                                                                                         \
@@ -535,10 +565,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
                 sc[k][i] = fast_exp2(sc[k][i] - m_safe);                                                           \
                 ls += sc[k][i];                                                                                    \
             }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            scr[i] = fast_exp2(scr[i] - m_safe);                                                                   \
+            ls += scr[i];                                                                                          \
+        }                                                                                                          \
         l_run = l_run * alpha + ls;                                                                                \
         m_run = m_new;                                                                                             \
         if (FIRST) {                                                                                               \
-            RESID_PARTIAL()                                                                                        \
+            STAMP(24);                                                                                             \
             if (append_wave) {                                                                                     \
                 int row_n = rstart + r_old;                                                                        \
                 row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;                                                  \
@@ -548,7 +582,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             }                                                                                                      \
             v4u *ld = (v4u *)(smem + kVBase);                                                                      \
             _Pragma("unroll") for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabv[i];        \
+            STAMP(12);                                                                                             \
             __syncthreads();                                                                                       \
+            STAMP(13);                                                                                             \
+            if (has_res) value_res_tile(rt, scr, O);                                                               \
         }                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < kRing; ++k) {                                                        \
             const int j = (PASS) * kRing + k;                                                                      \
@@ -565,56 +602,16 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     // last group: masked, no refills
     if (n_pass > 1) GROUP(n_pass - 1, true, false, false)
 #undef GROUP
-#undef RESID_PARTIAL
+#undef ISSUE_AFTER_UNIT
 #undef UNIT_T
-    // residual groups beyond the LDS-staged ones (only when a split holds more than 32 window rows):
-    // slow path, loads inside; each becomes a partial merged online into (m_late, l_late, olate)
-    float m_late = -INFINITY, l_late = 0.f, olate[kMaxG][2];
-#pragma unroll
-    for (int g = 0; g < kMaxG; ++g) olate[g][0] = olate[g][1] = 0.f;
-    for (int gi = kResWaves + wave; gi < rgroups; gi += kNW) {
-        const int i_lane = gi * 16 + c16;
-        const int j_lane = split + (i_lane < rcnt ? i_lane : 0) * p.nsplit;
-        int row_l = rstart + j_lane;
-        row_l = row_l >= p.rcap ? row_l - p.rcap : row_l;      // rstart, j < rcap: one wrap at most
-        const f16 *kp = (p.k_new && j_lane == r_old ? p.k_new + (long long)bh * 128 : kr + (long long)row_l * 128) + 32 * q4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) rk[s] = *(const v4u *)(kp + 8 * s);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ii = gi * 16 + i;
-            const int j = split + (ii < rcnt ? ii : 0) * p.nsplit;
-            int row_i = rstart + j;
-            row_i = row_i >= p.rcap ? row_i - p.rcap : row_i;
-            rv[i] = *(const h2 *)((p.v_new && j == r_old ? p.v_new + (long long)bh * 128 : vr + (long long)row_i * 128) + 2 * lane);
-        }
-        const int nv = rcnt - gi * 16;
-        float mr, lr, ores[kMaxG][2];
-        resid_group(rk, rv, nv < 16 ? nv : 16, qb, p.scale_log2e, G, lane, mr, lr, ores);
-        // (m, l) of head g live in lane g; the O_res rows live per lane -> broadcast the scale factors
-#pragma unroll
-        for (int g = 0; g < kMaxG; ++g)
-            if (g < G) {
-                const float mg = __shfl(mr, g, 64), ml = __shfl(m_late, g, 64);
-                const float mn = fmaxf(mg, ml), ms = mn > -INFINITY ? mn : 0.f;
-                const float fa = fast_exp2(ml - ms), fb = fast_exp2(mg - ms);
-                olate[g][0] = olate[g][0] * fa + ores[g][0] * fb;
-                olate[g][1] = olate[g][1] * fa + ores[g][1] * fb;
-            }
-        {
-            const float mn = fmaxf(mr, m_late), ms = mn > -INFINITY ? mn : 0.f;
-            l_late = l_late * fast_exp2(m_late - ms) + lr * fast_exp2(mr - ms);
-            m_late = mn;
-        }
-    }
-    MILLION_STAMP(p, 3);
+    STAMP(3);
     // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
     l_run = rows_sum(l_run);
     __syncthreads();
-    MILLION_STAMP(p, 4);
+    STAMP(4);
     const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
-    float *scr = (float *)smem;
-    float *mine = scr + wave * wstride;
+    float *scr_l = (float *)smem;
+    float *mine = scr_l + wave * wstride;
     {
         const bool hi = lane >= 32;
         const int c32 = lane & 31;
@@ -633,22 +630,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             mine[G * 128 + kMaxG + lane] = l_run;
         }
     }
-    // late residual partial of this wave: fold into the wave's entry (same wave: LDS ops are ordered)
-    if (kResWaves + wave < rgroups) {
-#pragma unroll
-        for (int g = 0; g < kMaxG; ++g)
-            if (g < G) {
-                const float mw_ = mine[G * 128 + g], ml = __shfl(m_late, g, 64), ll = __shfl(l_late, g, 64);
-                const float mn = fmaxf(mw_, ml), ms = mn > -INFINITY ? mn : 0.f;
-                const float fa = fast_exp2(mw_ - ms), fb = fast_exp2(ml - ms);
-                mine[g * 128 + 2 * lane] = mine[g * 128 + 2 * lane] * fa + olate[g][0] * fb;
-                mine[g * 128 + 2 * lane + 1] = mine[g * 128 + 2 * lane + 1] * fa + olate[g][1] * fb;
-                if (lane == 0) {
-                    mine[G * 128 + kMaxG + g] = mine[G * 128 + kMaxG + g] * fa + ll * fb;
-                    mine[G * 128 + g] = mn;
-                }
-            }
-    }
     __syncthreads();
     float *part = (float *)(smem + kPartOff);
     int *flag = (int *)(part + G * 128 + 2 * G + 4);
@@ -657,25 +638,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         float mw[kNW], vw[kNW], lw[kNW];
 #pragma unroll
         for (int w = 0; w < kNW; ++w) {
-            mw[w] = scr[w * wstride + G * 128 + g];
-            vw[w] = scr[w * wstride + e];
-            lw[w] = scr[w * wstride + G * 128 + kMaxG + g];
-        }
-        // LDS-staged residual partials (groups 0..kResWaves-1)
-        float mr[kResWaves], vr_[kResWaves], lr[kResWaves];
-#pragma unroll
-        for (int w = 0; w < kResWaves; ++w) {
-            const bool on = w < rgroups;
-            const float *ml = (const float *)(smem + kResML) + w * 16;
-            mr[w] = on ? ml[g] : -INFINITY;
-            lr[w] = on ? ml[8 + g] : 0.f;
-            vr_[w] = on ? ((const float *)(smem + kResOut + w * 4096))[e] : 0.f;
+            mw[w] = scr_l[w * wstride + G * 128 + g];
+            vw[w] = scr_l[w * wstride + e];
+            lw[w] = scr_l[w * wstride + G * 128 + kMaxG + g];
         }
         float Mx = mw[0];
 #pragma unroll
         for (int w = 1; w < kNW; ++w) Mx = fmaxf(Mx, mw[w]);
-#pragma unroll
-        for (int w = 0; w < kResWaves; ++w) Mx = fmaxf(Mx, mr[w]);
         const float Ms = Mx > -INFINITY ? Mx : 0.f;
         float acc = 0.f, lsum = 0.f;
 #pragma unroll
@@ -684,12 +653,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
             acc = fmaf(f, vw[w], acc);
             lsum = fmaf(f, lw[w], lsum);
         }
-#pragma unroll
-        for (int w = 0; w < kResWaves; ++w) {
-            const float f = fast_exp2(mr[w] - Ms);
-            acc = fmaf(f, vr_[w], acc);
-            lsum = fmaf(f, lr[w], lsum);
-        }
         part[e] = acc;
         if ((e & 127) == 0) {
             part[G * 128 + g] = Mx;
@@ -697,9 +660,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         }
     }
     __syncthreads();
-    MILLION_STAMP(p, 5);
-    publish_and_merge(p, b, hk, split, part, scr, flag);
+    STAMP(5);
+    publish_and_merge(p, b, hk, split, part, scr_l, flag);
     MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
+    if (dbg_on && lane < kStampSlots) {              // copy this wave's LDS stamps out (slots it wrote)
+        const unsigned long long v =
+            *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8);
+        if (v) p.dbg[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves + wave) * kStampSlots + lane] = v;
+    }
+#undef STAMP
 }
 
 // Self-check of the row-swap reductions (tests/test_gpu_parity.py): one wave, in[64] -> max / sum over the
@@ -714,7 +683,10 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
     return hipGetLastError() == hipSuccess ? MILLION_OK : MILLION_ERR_LAUNCH;
 }
 
-bool attn_mfma_shape_ok(const AttnParams &p) { return p.d == 128 && p.M == 64 && p.C == 256 && p.G <= kMaxG; }
+// rcap <= kNW * kResRows: every window row of a split has a slot in some wave's residual tile
+bool attn_mfma_shape_ok(const AttnParams &p) {
+    return p.d == 128 && p.M == 64 && p.C == 256 && p.G <= kMaxG && p.rcap <= kNW * kResRows;
+}
 
 bool attn_mfma_supported(const AttnParams &p) {
     return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);

@@ -84,12 +84,15 @@ __device__ __forceinline__ long long v_page_id(const AttnParams &p, int bh, int 
     return p.ids64 ? p.v_ids64[idx] : (long long)p.v_ids32[idx];
 }
 
-// Diagnostic stamps (off unless a buffer is set): lane 0 of each workgroup stores the 100 MHz realtime
-// counter at phase boundaries; 16 slots per workgroup.  Never read by any kernel.
+// Diagnostic stamps (off unless a buffer is set): lane 0 of each of the first 8 waves of a workgroup stores the
+// 100 MHz realtime counter at phase boundaries; 32 slots per wave, layout [workgroup][wave][slot].  Never
+// read by any kernel.
+constexpr int kStampWaves = 8, kStampSlots = 32;
 #define MILLION_STAMP(p, i)                                                                              \
     do {                                                                                                 \
-        if ((p).dbg && threadIdx.x == 0)                                                                 \
-            (p).dbg[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if ((p).dbg && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < kStampWaves)                      \
+            (p).dbg[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves + (threadIdx.x >> 6)) * kStampSlots + (i)] = \
+                __builtin_amdgcn_s_memrealtime();                                                        \
     } while (0)
 
 // ---- inter-workgroup hand-off of split partials (cdna_hip_programming.md, Guideline 16, R1 counter form) ----

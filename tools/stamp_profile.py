@@ -36,7 +36,8 @@ vc = ops.prepare_cents(torch.randn(M, C, 2, device=dev).half())
 q = torch.randn(bs, nh, 1, d, device=dev).half()
 kr = torch.randn(bs, nhk, 128, d, device=dev).half()
 vr = torch.randn(bs, nhk, 128, d, device=dev).half()
-stamps = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
+NW, NS = 8, 32                               # common.h: kStampWaves, kStampSlots
+stamps = torch.zeros(bs * nhk * 64 * NW * NS, dtype=torch.int64, device=dev)
 
 
 def run(l):
@@ -54,27 +55,36 @@ for i in range(args.layers):
     stamps.zero_()
     run(i)
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 16)
-    s = s[s[:, 0] != 0]
-    spans.append((s[:, 6].max() - s[:, 0].min()) / 100.0)
+    s = stamps.cpu().numpy().reshape(-1, NW, NS)
+    s = s[s[:, 0, 0] != 0]
+    spans.append((s[:, :, 6].max() - s[:, :, 0].min()) / 100.0)
     last = s
 lib.million_debug_set_stamp_buffer(None)
 # stamp ids in program order, and what ends at each
-order = [(0, "kernel start"), (7, "q + K codebook + code unit 0 requested"), (8, "K codebook written to LDS"),
-         (1, "barrier 1 (K codebook)"), (9, "rest requested: residual rows, units 1-3, V codebook"),
-         (2, "accumulators initialised"), (3, "all groups done (score pass, V-codebook barrier, value pass)"),
+order = [(0, "kernel start"), (7, "q + K codebook + K bytes of the ring requested"), (8, "K codebook written to LDS"),
+         (1, "barrier 1 (K codebook)"), (2, "accumulators initialised"),
+         (16, "score unit 0"), (17, "  issue: V bytes units 0-1"), (18, "score unit 1"),
+         (19, "  issue: V bytes units 2-3"), (20, "score unit 2"), (21, "  issue: V codebook"), (22, "score unit 3"),
+         (24, "residual tile scores, softmax update"), (12, "append store, V codebook -> LDS"),
+         (13, "barrier 2"), (3, "residual tile values, value pass (+ later groups)"),
          (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
 s = last
-t0 = s[:, 0].min()
+t0 = s[:, :, 0].min()
 print(f"workgroups {s.shape[0]}; kernel span (first start -> last end) per launch [us]: {[round(float(x), 2) for x in spans]}")
-print("start skew of workgroups [us]: max %.2f" % ((s[:, 0].max() - t0) / 100.0))
-prev = 0
-for sid, name in order[1:]:
-    d = (s[:, sid] - s[:, prev]) / 100.0
-    print(f"  +{d.mean():6.2f} us (min {d.min():5.2f} max {d.max():5.2f})  -> {name}")
-    prev = sid
-la = s[s[:, 11] != 0]
+print("start skew of workgroups [us]: max %.2f" % ((s[:, 0, 0].max() - t0) / 100.0))
+for name, sel in (("waves 0-3 (carry a residual tile at r=100, 32 splits)", s[:, :4, :].reshape(-1, NS)), ("waves 4-7", s[:, 4:, :].reshape(-1, NS))):
+    print(f"--- {name}: mean time since that wave's start, and step duration [us]")
+    prev = 0
+    for sid, label in order[1:]:
+        if (sel[:, sid] == 0).all():
+            continue
+        at = (sel[:, sid] - sel[:, 0]) / 100.0
+        d = (sel[:, sid] - sel[:, prev]) / 100.0
+        print(f"  @{at.mean():6.2f}  +{d.mean():5.2f} (min {d.min():5.2f} max {d.max():5.2f})  {label}")
+        prev = sid
+la = s[:, 0, :][s[:, 0, 11] != 0]
 if la.shape[0]:
     print("  last arrivers (%d): ticket -> weights ready %.2f | -> out written %.2f us" % (
         la.shape[0], ((la[:, 11] - la[:, 10]) / 100.0).mean(), ((la[:, 6] - la[:, 11]) / 100.0).mean()))
-print("  end relative to first start: mean %.2f max %.2f us" % (((s[:, 6] - t0) / 100.0).mean(), ((s[:, 6] - t0) / 100.0).max()))
+e = (s[:, 0, 6] - t0) / 100.0
+print("  end relative to first start: mean %.2f max %.2f us" % (e.mean(), e.max()))
