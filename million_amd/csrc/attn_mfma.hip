@@ -54,6 +54,18 @@ struct UnitCodes {
 __device__ __forceinline__ unsigned lds32(unsigned addr) {
     return *(const __attribute__((address_space(3))) unsigned *)(size_t)addr;
 }
+// Diagnostic stamps go to LDS (lane 0 of each wave) and are copied out at the very end of the kernel: a global
+// store per stamp would put a vmcnt(0) into the phases being timed (and a generic-pointer store a FLAT op,
+// which makes hipcc wait vmcnt(0) on the non-diagnostic path too).
+__device__ __forceinline__ void stamp_lds(bool on, int lane, int wave, int i) {
+    if (on && lane == 0)
+        *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + i) * 8) =
+            __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void stamp_lds_clear(bool on, int lane, int wave) {
+    if (on && lane < kStampSlots)
+        *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8) = 0ull;
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 
 // Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row swaps:
@@ -379,6 +391,77 @@ __device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&p
     }
 }
 
+// ---- tail shared by the MFMA kernels: merge the waves of the workgroup through LDS (the tables are dead after
+//      the first barrier), publish the split's partial, merge the splits in the last-arriving workgroup ----
+__device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *smem, int b, int hk, int split, int G, int tid,
+                                                  int lane, int wave, bool dbg_on, v16f32 (&O)[2][2], float m_run, float l_run) {
+#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
+    // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
+    l_run = rows_sum(l_run);
+    __syncthreads();
+    STAMP(4);
+    const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
+    float *scr_l = (float *)smem;
+    float *mine = scr_l + wave * wstride;
+    {
+        const bool hi = lane >= 32;
+        const int c32 = lane & 31;
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const int g = hi ? 4 + rho : rho;
+            if (g < G) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) mine[g * 128 + 2 * (32 * n + c32) + kk] = O[n][kk][rho];
+            }
+        }
+        if (lane < G) {                                  // lane g: row q' = 0, col g
+            mine[G * 128 + lane] = m_run;
+            mine[G * 128 + kMaxG + lane] = l_run;
+        }
+    }
+    __syncthreads();
+    float *part = (float *)(smem + kPartOff);
+    int *flag = (int *)(part + G * 128 + 2 * G + 4);
+    for (int e = tid; e < G * 128; e += kNW * 64) {
+        const int g = e >> 7;
+        float mw[kNW], vw[kNW], lw[kNW];
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) {
+            mw[w] = scr_l[w * wstride + G * 128 + g];
+            vw[w] = scr_l[w * wstride + e];
+            lw[w] = scr_l[w * wstride + G * 128 + kMaxG + g];
+        }
+        float Mx = mw[0];
+#pragma unroll
+        for (int w = 1; w < kNW; ++w) Mx = fmaxf(Mx, mw[w]);
+        const float Ms = Mx > -INFINITY ? Mx : 0.f;
+        float acc = 0.f, lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) {
+            const float f = fast_exp2(mw[w] - Ms);      // -inf -> 0
+            acc = fmaf(f, vw[w], acc);
+            lsum = fmaf(f, lw[w], lsum);
+        }
+        part[e] = acc;
+        if ((e & 127) == 0) {
+            part[G * 128 + g] = Mx;
+            part[G * 128 + G + g] = lsum;
+        }
+    }
+    __syncthreads();
+    STAMP(5);
+    publish_and_merge(p, b, hk, split, part, scr_l, flag);
+    MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
+    if (dbg_on && lane < kStampSlots) {              // copy this wave's LDS stamps out (slots it wrote)
+        const unsigned long long v =
+            *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8);
+        if (v) p.dbg[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves + wave) * kStampSlots + lane] = v;
+    }
+#undef STAMP
+}
+
 template <bool HAS_CODES>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -392,17 +475,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     v4i dl = {p.T, p.r, p.rstart, 0};
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    // Diagnostic stamps go to LDS (lane 0 of each wave) and are copied out at the very end: a global store
-    // per stamp would put a vmcnt(0) into the phases being timed.
     const bool dbg_on = p.dbg != nullptr;
-#define STAMP(i)                                                                                                   \
-    do {                                                                                                           \
-        if (dbg_on && lane == 0)                                                                                   \
-            *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(                            \
-                kStampOff + (wave * kStampSlots + (i)) * 8) = __builtin_amdgcn_s_memrealtime();                    \
-    } while (0)
-    if (dbg_on && lane < kStampSlots)
-        *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8) = 0ull;
+#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
+    stamp_lds_clear(dbg_on, lane, wave);
     STAMP(0);
     const int q4 = lane >> 4, c16 = lane & 15;
 
@@ -605,69 +680,333 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #undef ISSUE_AFTER_UNIT
 #undef UNIT_T
     STAMP(3);
-    // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
-    l_run = rows_sum(l_run);
-    __syncthreads();
-    STAMP(4);
-    const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
-    float *scr_l = (float *)smem;
-    float *mine = scr_l + wave * wstride;
-    {
-        const bool hi = lane >= 32;
-        const int c32 = lane & 31;
+    merge_and_publish(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
+#undef STAMP
+}
+
+// ---- value side of a 32-token unit in pieces, for the pipelined kernel ---------------------------------
+// value_prep: probabilities (score layout: pr[g2*4 + rho] = token 16*g2 + 4*q' + rho for the head of this lane's
+// column) -> A operands P[s][0..3] of the two token steps (rows = heads, K = 16 tokens).
+__device__ __forceinline__ void value_prep(const float (&pr)[8], unsigned (&P)[2][4]) {
+    unsigned pk[2][2];    // pk[g2][i]: tokens 16*g2 + 4*q' + {2i, 2i+1} as packed fp16
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            h2 t = {(f16)pr[g2 * 4 + 2 * i], (f16)pr[g2 * 4 + 2 * i + 1]};
+            pk[g2][i] = __builtin_bit_cast(unsigned, t);
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const v2u x = __builtin_amdgcn_permlane32_swap(pk[0][i], pk[1][i], false, false);
+        // x[0] = {grp0 rows 0,1 | grp1 rows 0,1}  (step 0)   x[1] = {grp0 rows 2,3 | grp1 rows 2,3}  (step 1)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const v2u y = swap16_self(x[s]);
+            P[s][i] = y[0];          // rows {0,0,2,2} of x[s]
+            P[s][2 + i] = y[1];      // rows {1,1,3,3} of x[s]
+        }
+    }
+}
+// the 8 centroid gathers of value step st = 2n + s (subspaces 32n.., tokens 16h + 8s + j)
+__device__ __forceinline__ void v_gather(const v4u (&vc)[2], int st, unsigned vconst0, unsigned vconst1, unsigned (&e)[8]) {
+    const unsigned vconst = (st >> 1) ? vconst1 : vconst0;
+    const unsigned w0 = vc[st >> 1][2 * (st & 1)], w1 = vc[st >> 1][2 * (st & 1) + 1];
+    e[0] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020400u));
+    e[1] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020500u));
+    e[2] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020600u));
+    e[3] = lds32(__builtin_amdgcn_perm(w0, vconst, 0x03020700u));
+    e[4] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020400u));
+    e[5] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020500u));
+    e[6] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020600u));
+    e[7] = lds32(__builtin_amdgcn_perm(w1, vconst, 0x03020700u));
+}
+// pack the gathered centroids (even dims -> B0, odd dims -> B1) and accumulate
+__device__ __forceinline__ void v_step(const unsigned (&e)[8], const unsigned (&Ps)[4], v16f32 (&On)[2]) {
+    const v8f16 B0 = as_v8f16(__builtin_amdgcn_perm(e[1], e[0], 0x05040100u), __builtin_amdgcn_perm(e[3], e[2], 0x05040100u),
+                              __builtin_amdgcn_perm(e[5], e[4], 0x05040100u), __builtin_amdgcn_perm(e[7], e[6], 0x05040100u));
+    const v8f16 B1 = as_v8f16(__builtin_amdgcn_perm(e[1], e[0], 0x07060302u), __builtin_amdgcn_perm(e[3], e[2], 0x07060302u),
+                              __builtin_amdgcn_perm(e[5], e[4], 0x07060302u), __builtin_amdgcn_perm(e[7], e[6], 0x07060302u));
+    const v8f16 A = as_v8f16(Ps[0], Ps[1], Ps[2], Ps[3]);
+    On[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B0, On[0], 0, 0, 0);
+    On[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B1, On[1], 0, 0, 0);
+}
+
+// =====================================================================================================
+// Pipelined kernel.
+//
+// Why a second kernel: in the grouped kernel above a wave runs "score pass of 4 units" (LDS-bound: ~7 LDS
+// cycles per random K gather), then "value pass of 4 units" (issue-bound: v_perm address + pack work and the
+// 32x32x16 MFMAs), one after the other, and with one workgroup per CU nothing else fills the idle pipe.
+// Here both codebooks are in LDS before the loop, the softmax is online PER UNIT, and the value steps of unit
+// u are interleaved instruction by instruction with the score stages of unit u + 1, so the LDS pipe and the
+// vector/matrix issue work at the same time.  Loads: everything is requested at the top (tables first).
+// =====================================================================================================
+// online softmax over N new scores of this lane's column (head): updates (m_run, l_run), rescales O when a
+// running maximum moves, turns the scores into probabilities in place
+template <int N>
+__device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, float &l_run, v16f32 (&O)[2][2], int G, int lane) {
+    float mx = sc[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) mx = fmaxf(mx, sc[i]);
+    mx = rows_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+    const float alpha = fast_exp2(m_run - m_safe);
+    if (__any(m_new > m_run && m_run > -INFINITY)) {
+        // alpha of head g sits in lane g; O rows: lanes < 32 hold heads rho, lanes >= 32 heads 4 + rho
 #pragma unroll
         for (int rho = 0; rho < 4; ++rho) {
-            const int g = hi ? 4 + rho : rho;
-            if (g < G) {
+            const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
+            const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;
+            const float f = lane < 32 ? flo : fhi;
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) mine[g * 128 + 2 * (32 * n + c32) + kk] = O[n][kk][rho];
+                for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
+        }
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sc[i] = fast_exp2(sc[i] - m_safe);
+        ls += sc[i];
+    }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+}
+
+template <bool HAS_CODES>
+__global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int bh = blockIdx.y;
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int G = p.G;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i dl = {p.T, p.r, p.rstart, 0};
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const bool dbg_on = p.dbg != nullptr;
+#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
+    stamp_lds_clear(dbg_on, lane, wave);
+    STAMP(0);
+    const int q4 = lane >> 4, c16 = lane & 15;
+
+    v8f16 qb[4];
+    {
+        const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            v4u t = *(const v4u *)(qv + 8 * s);
+            if (c16 >= G) t = v4u{0, 0, 0, 0};
+            qb[s] = __builtin_bit_cast(v8f16, t);
+        }
+    }
+    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
+    h2 new_k = {}, new_v = {};
+    if (append_wave) {
+        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
+    }
+    // ---- request order = need order, and not everything up front: the CU's load path takes ~25 cycles per
+    //      1-KiB wave request (measured: 12 more requests per wave in front of the barrier moved it by 1.7 us),
+    //      so only what the first scores need is requested before the K-codebook barrier - the first unit's
+    //      code bytes (HBM latency) ahead of the codebook (L2) - and the rest rides between compute stages. ----
+    if (p.dev_lengths)
+        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
+    int T = dl[0] < p.T ? dl[0] : p.T;
+    const int r_old = dl[1], rstart = dl[2];
+    const int r = r_old + (p.k_new ? 1 : 0);
+    if (T < 1) T = 0;
+    const int t_begin = min(split * p.split_len, T);
+    const int t_end = min(t_begin + p.split_len, T);
+    const int n_units = (t_end - t_begin + 31) >> 5;
+    const int n_mine = n_units > wave ? (n_units - wave + kNW - 1) / kNW : 0;
+    const int T_ld = T > 0 ? T : 1;
+    const int t_last = (T_ld - 1) & ~31;
+    // unit j of this wave starts at token t_begin + 32*(wave + j*kNW); slots past the last unit re-request the
+    // unit that holds token T-1 (L2 hits), so that no code load sits in a conditional (counted waits)
+#define UNIT_T(j) ((j) < n_mine ? t_begin + 32 * (wave + (j) * kNW) : t_last)
+    UnitCodes ring[kRing];
+    PidPair pid4[kRing];
+    {
+        int pg[kRing];
+#pragma unroll
+        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
+        load_pids4(p, bh, pg, pid4);
+    }
+    load_unit_k(p, b, hk, pid4[0], UNIT_T(0), T_ld, lane, ring[0]);
+    load_unit_v(p, pid4[0], UNIT_T(0), lane, ring[0]);
+    v4u tabk[8], tabv[8];
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
+    {
+        const v4u *ks = (const v4u *)p.k_tab;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+    }
+    load_unit_k(p, b, hk, pid4[1], UNIT_T(1), T_ld, lane, ring[1]);
+    load_unit_v(p, pid4[1], UNIT_T(1), lane, ring[1]);
+
+    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
+    const bool has_res = wave < rcnt;
+    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    ResTile rt;
+    if (has_res) load_res_tile(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+    STAMP(7);
+    {
+        v4u *ld = (v4u *)smem;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabk[i];
+    }
+    STAMP(8);
+    __syncthreads();
+    STAMP(1);
+
+    float m_run = -INFINITY, l_run = 0.f;
+    v16f32 O[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
+    if (append_wave) {
+        int row_n = rstart + r_old;
+        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
+        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
+        *(h2 *)(p.k_res_w + o) = new_k;
+        *(h2 *)(p.v_res_w + o) = new_v;
+    }
+    // residual tile of this wave first: it needs neither codebook
+    if (has_res) {
+        float scr[4];
+        score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
+        softmax_online<4>(scr, m_run, l_run, O, G, lane);
+        value_res_tile(rt, scr, O);
+    }
+    STAMP(2);
+
+    const unsigned kbase = (unsigned)q4 * 16u * 1024u;
+    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);
+    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);
+
+    // ---- the pipeline.  Unit u lives in ring slot u & 3.  a[]: K gathers of 2 score stages in flight; e[]: V
+    //      gathers of 2 value steps.  LDS results come back in issue order: every wait is a counted lgkmcnt.
+    //      BLOCK(u): the 4 value steps of unit u interleaved with the 8 score stages of unit u + 1 (stage st's
+    //      MFMA is followed at once by the gathers of stage st + 2 into the same registers); the first gathers of
+    //      the next block go out before the softmax bubble; LOADS = the global requests that ride in this block.
+    //      (K gathers prefetched for a unit that does not exist read stale code bytes - any byte is a valid
+    //      code - and are never consumed.) ----
+    unsigned a[2][4], e[2][8], P[2][4];
+    float sc[8];
+#define KG(SL, ST) k_gather(ring[SL].k[(ST) >> 2][(ST) & 3], kbase + ((ST) & 3) * 4096, a[(ST) & 1])
+#define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
+        as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
+#define VG(SL, I) v_gather(ring[SL].v, I, vconst0, vconst1, e[(I) & 1])
+#define VS(I) v_step(e[(I) & 1], P[(I) & 1], O[(I) >> 1])
+#define SCORES_OUT(u)                                                                                              \
+    _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                               \
+        _Pragma("unroll") for (int rho = 0; rho < 4; ++rho) {                                                      \
+            const int tok = t_begin + 32 * (wave + (u) * kNW) + 16 * g2 + 4 * q4 + rho;                             \
+            sc[g2 * 4 + rho] = tok < t_end ? D[g2][rho] * p.scale_log2e : -INFINITY;                               \
+        }
+#define BLOCK(U4, u, LOADS)                                                                                        \
+    {                                                                                                              \
+        v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            VS(i);                                                                                                 \
+            if (i < 3) VG(U4, i + 1);                                                                              \
+            KM(2 * i);                                                                                             \
+            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 2);                                                              \
+            KM(2 * i + 1);                                                                                         \
+            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 3);                                                              \
+            if (i == 0) { LOADS }                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+        VG(((U4) + 1) & 3, 0);                                                                                     \
+        KG(((U4) + 2) & 3, 0);                                                                                     \
+        KG(((U4) + 2) & 3, 1);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        SCORES_OUT((u) + 1)                                                                                        \
+        softmax_online<8>(sc, m_run, l_run, O, G, lane);                                                           \
+        value_prep(sc, P);                                                                                         \
+    }
+#define VALUE_ALONE(U4)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        if (i < 3) VG(U4, i + 1);                                                                                  \
+        VS(i);                                                                                                     \
+    }
+    {
+        // Every wave runs the 4-unit chain straight through (a unit the wave does not have re-reads the unit
+        // holding token T - 1 and is masked to -inf: the host picks this kernel only when a split holds 25..40
+        // units, so that is at most one unit per wave); a wave with a fifth unit appends one block.
+        PidPair pid5 = pid4[0];
+        if (n_mine > kRing) pid5 = load_pids(p, bh, UNIT_T(kRing) >> p.ps_shift);      // wave-uniform, rare
+        // prologue: the 8 score stages of unit 0; the V codebook and the next code bytes are requested in between
+        {
+            const v4u *vs = (const v4u *)p.v_tab_col;
+            v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            KG(0, 0);
+            KG(0, 1);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                // the codebook requests first: its LDS store waits for everything requested before it, and
+                // must not wait for HBM-bound code bytes
+                if (st < 4) {
+                    tabv[2 * st] = vs[((2 * st + rot) & 7) * (kNW * 64) + tid];
+                    tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & 7) * (kNW * 64) + tid];
+                }
+                KM(st);
+                if (st + 2 < 8) KG(0, st + 2);
+                if (st == 4) load_unit_k(p, b, hk, pid4[2], UNIT_T(2), T_ld, lane, ring[2]);
+                if (st == 6) load_unit_v(p, pid4[2], UNIT_T(2), lane, ring[2]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            SCORES_OUT(0)
         }
-        if (lane < G) {                                  // lane g: row q' = 0, col g
-            mine[G * 128 + lane] = m_run;
-            mine[G * 128 + kMaxG + lane] = l_run;
+        softmax_online<8>(sc, m_run, l_run, O, G, lane);
+        value_prep(sc, P);
+        STAMP(16);
+        {
+            v4u *ldv = (v4u *)(smem + kVBase);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ldv[((i + rot) & 7) * (kNW * 64) + tid] = tabv[i];
+        }
+        STAMP(12);
+        __syncthreads();
+        STAMP(13);
+        VG(0, 0);
+        KG(1, 0);
+        KG(1, 1);
+        BLOCK(0, 0, load_unit_k(p, b, hk, pid4[3], UNIT_T(3), T_ld, lane, ring[3]);
+                    load_unit_v(p, pid4[3], UNIT_T(3), lane, ring[3]);)
+        if (n_mine > kRing) load_unit_pid(p, b, hk, pid5, UNIT_T(kRing), T_ld, lane, ring[0]);
+        STAMP(17);
+        BLOCK(1, 1, )
+        STAMP(18);
+        BLOCK(2, 2, )
+        STAMP(19);
+        if (n_mine > kRing) {
+            BLOCK(3, 3, )
+            VALUE_ALONE(0)
+        } else {
+            VALUE_ALONE(3)
         }
     }
-    __syncthreads();
-    float *part = (float *)(smem + kPartOff);
-    int *flag = (int *)(part + G * 128 + 2 * G + 4);
-    for (int e = tid; e < G * 128; e += kNW * 64) {
-        const int g = e >> 7;
-        float mw[kNW], vw[kNW], lw[kNW];
-#pragma unroll
-        for (int w = 0; w < kNW; ++w) {
-            mw[w] = scr_l[w * wstride + G * 128 + g];
-            vw[w] = scr_l[w * wstride + e];
-            lw[w] = scr_l[w * wstride + G * 128 + kMaxG + g];
-        }
-        float Mx = mw[0];
-#pragma unroll
-        for (int w = 1; w < kNW; ++w) Mx = fmaxf(Mx, mw[w]);
-        const float Ms = Mx > -INFINITY ? Mx : 0.f;
-        float acc = 0.f, lsum = 0.f;
-#pragma unroll
-        for (int w = 0; w < kNW; ++w) {
-            const float f = fast_exp2(mw[w] - Ms);      // -inf -> 0
-            acc = fmaf(f, vw[w], acc);
-            lsum = fmaf(f, lw[w], lsum);
-        }
-        part[e] = acc;
-        if ((e & 127) == 0) {
-            part[G * 128 + g] = Mx;
-            part[G * 128 + G + g] = lsum;
-        }
-    }
-    __syncthreads();
-    STAMP(5);
-    publish_and_merge(p, b, hk, split, part, scr_l, flag);
-    MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
-    if (dbg_on && lane < kStampSlots) {              // copy this wave's LDS stamps out (slots it wrote)
-        const unsigned long long v =
-            *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8);
-        if (v) p.dbg[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves + wave) * kStampSlots + lane] = v;
-    }
+#undef KG
+#undef KM
+#undef VG
+#undef VS
+#undef SCORES_OUT
+#undef BLOCK
+#undef VALUE_ALONE
+#undef UNIT_T
+    STAMP(3);
+    merge_and_publish(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
 #undef STAMP
 }
 
@@ -691,6 +1030,9 @@ bool attn_mfma_shape_ok(const AttnParams &p) {
 bool attn_mfma_supported(const AttnParams &p) {
     return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
 }
+
+static bool g_mfma_no_pipe = false;
+void set_mfma_no_pipe(bool on) { g_mfma_no_pipe = on; }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     AttnParams p = p_in;
@@ -718,9 +1060,13 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_mfma_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         attr_set = true;
     }
-    if (p.T > 0)
+    // the pipelined kernel runs every wave through 4 units (+ a fifth where it exists): splits of 25..40 units
+    if (!g_mfma_no_pipe && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
+        hipLaunchKernelGGL(attn_mfma_pipe_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+    else if (p.T > 0)
         hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else
         hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);

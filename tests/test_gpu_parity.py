@@ -405,3 +405,52 @@ def test_harness_graph_replay_matches_eager(env):
     same = sum(a == b for a, b in zip(toks["eager"], toks["graph"]))
     assert same >= steps - 4, f"graph replay diverges from eager: {same}/{steps} tokens equal"
     assert len(set(toks["eager"])) > 4          # not a degenerate constant sequence
+
+
+# ---- long contexts: the pipelined MFMA kernel (splits of 25..40 units of 32 tokens; 32 splits per kv head at
+#      bs * nh_k = 8 on a 256-CU part) --------------------------------------------------------------------------
+@pytest.mark.parametrize("T,r,nh,nhk", [
+    (32768, 100, 32, 8),    # headline shape: 4 units per wave, no phantom units
+    (32832, 128, 32, 8),    # one page more: waves 0-1 of every split carry a fifth unit
+    (24608, 3, 32, 8),      # 26 units per split: waves with 3 units run one masked phantom unit
+    (40960, 77, 8, 8),      # 40 units per split: every wave has five; G = 1
+    (33000, 128, 64, 8),    # ragged end inside a unit; G = 8
+    (40961, 5, 32, 8),      # one token past the pipelined range: grouped kernel, several groups per wave
+])
+def test_attn_long_context(T, r, nh, nhk, env, oracle):
+    torch, ops = env
+    c = synth.attn_case(4000 + T % 977 + r, 1, nh, nhk, 128, 64, 256, T, r)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, f"paged T={T}")
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 128, k_paged=False, i64=True, shuffle=False), gold, f"mixed T={T}")
+
+
+def test_fused_append_long_context_device_lengths(env, oracle):
+    """Fused append + device-resident lengths on the pipelined kernel, crossing the 4 -> 5 units per wave boundary
+    (the host bound n_tokens sizes the grid; the kernel reads T, r, start from the device)."""
+    torch, ops = env
+    bs, nh, nhk, ps, cap = 1, 32, 8, 64, 128
+    T0, r0, start = 32768, 126, 70
+    c = synth.attn_case(4242, bs, nh, nhk, 128, 64, 256, T0 + 64, cap)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    kc, vc = torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda()
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    rs = np.random.RandomState(9)
+    k_hist, v_hist = c["k_res"].copy(), c["v_res"].copy()
+    for T, r in ((T0, r0), (T0 + 64, 60)):      # before / after a flush of one page (lengths rewritten on the device)
+        lengths = torch.tensor([[T, r, start, 0]] * bs, dtype=torch.int32, device="cuda")
+        k_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        v_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0, M=64, C=256, resid_start=start, dev_lengths=lengths,
+                                 k_new=torch.from_numpy(k_new).cuda(), v_new=torch.from_numpy(v_new).cuda(),
+                                 k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T0 + 64)
+        torch.cuda.synchronize()
+        k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
+        c2 = dict(c, k_codes=c["k_codes"][:, :, :T], v_codes=c["v_codes"][:, :, :T], k_res=k_hist, v_res=v_hist, r=r + 1)
+        _check(out.cpu().numpy(), oracle.decode_attn(**c2), f"T={T} r={r}")
+        assert lengths.cpu().numpy()[:, 1].tolist() == [r + 1] * bs

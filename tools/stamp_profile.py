@@ -19,6 +19,7 @@ ap.add_argument("--nhk", type=int, default=8)
 ap.add_argument("--bs", type=int, default=1)
 ap.add_argument("--r", type=int, default=100)
 ap.add_argument("--layers", type=int, default=8)
+ap.add_argument("--grouped", action="store_true", help="labels of the grouped kernel")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 M, C, d, ps = 64, 256, 128, 64
@@ -61,13 +62,22 @@ for i in range(args.layers):
     last = s
 lib.million_debug_set_stamp_buffer(None)
 # stamp ids in program order, and what ends at each
-order = [(0, "kernel start"), (7, "q + K codebook + K bytes of the ring requested"), (8, "K codebook written to LDS"),
-         (1, "barrier 1 (K codebook)"), (2, "accumulators initialised"),
-         (16, "score unit 0"), (17, "  issue: V bytes units 0-1"), (18, "score unit 1"),
-         (19, "  issue: V bytes units 2-3"), (20, "score unit 2"), (21, "  issue: V codebook"), (22, "score unit 3"),
-         (24, "residual tile scores, softmax update"), (12, "append store, V codebook -> LDS"),
-         (13, "barrier 2"), (3, "residual tile values, value pass (+ later groups)"),
-         (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
+if args.grouped:     # labels of the grouped kernel (attn_mfma_kernel)
+    order = [(0, "kernel start"), (7, "q + K codebook + K bytes of the ring requested"), (8, "K codebook written to LDS"),
+             (1, "barrier 1 (K codebook)"), (2, "accumulators initialised"),
+             (16, "score unit 0"), (17, "  issue: V bytes units 0-1"), (18, "score unit 1"),
+             (19, "  issue: V bytes units 2-3"), (20, "score unit 2"), (21, "  issue: V codebook"), (22, "score unit 3"),
+             (24, "residual tile scores, softmax update"), (12, "append store, V codebook -> LDS"),
+             (13, "barrier 2"), (3, "residual tile values, value pass (+ later groups)"),
+             (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
+else:                # labels of the pipelined kernel (attn_mfma_pipe_kernel)
+    order = [(0, "kernel start"), (7, "requested: q, unit 0 bytes, K codebook, K bytes unit 1, residual tile"),
+             (8, "K codebook written to LDS"), (1, "barrier 1 (K codebook)"), (2, "residual tile done"),
+             (16, "prologue: scores of unit 0 (+ V codebook / unit 1-2 requests), softmax"),
+             (12, "V codebook written to LDS"), (13, "barrier 2 (V codebook)"), (17, "block 0: values 0 | scores 1"),
+             (18, "block 1: values 1 | scores 2"), (19, "block 2: values 2 | scores 3"),
+             (3, "values of the last unit (+ block 3 where a fifth unit exists)"),
+             (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
 s = last
 t0 = s[:, :, 0].min()
 print(f"workgroups {s.shape[0]}; kernel span (first start -> last end) per launch [us]: {[round(float(x), 2) for x in spans]}")
