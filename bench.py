@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--force-generic", action="store_true", help="A/B: use the generic LUT kernel")
+    ap.add_argument("--kernel-policy", type=int, default=0, help="A/B: 2 = grouped MFMA kernel only, 3 = prefer the pipelined one")
     ap.add_argument("--roofline-launches", type=int, default=256)
     return ap.parse_args()
 
@@ -81,7 +82,7 @@ def main():
     from million_amd import ops, sharding
     from million_amd.pq_cache import PagedPQCache
 
-    ops.set_force_generic(args.force_generic)
+    ops.set_force_generic(1 if args.force_generic else args.kernel_policy)
     bs, nh, nhk, d, M, C, layers = args.batch_per_gpu, args.nh, args.nh_k, 128, args.M, 256, args.layers
     ps, cap = 64, 128
     T0 = args.ctx // ps * ps
@@ -194,7 +195,7 @@ def main():
                        "ctx": T0, "layers": layers, "M": M, "batch_per_gpu": bs, "parallelism": f"requests x{world}",
                        "flush_steps_in_timed_region": n_flush_steps,
                        "launch": "eager" if args.no_graph else "hipGraph replay",
-                       "kernel": "generic-LUT" if args.force_generic else "auto"},
+                       "kernel": "generic-LUT" if args.force_generic else ("auto" if not args.kernel_policy else f"policy{args.kernel_policy}")},
             "roofline": {"bound": "hbm", "kernel": "fused decode attention (one launch per layer-call)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -21,7 +21,7 @@ class EncodeDesc(ctypes.Structure):
                 ("x_row_start", c_i32), ("x_row_mod", c_i32),
                 ("dst_layout", c_i32), ("dst_token_start", c_i32),
                 ("dst_stride_b", c_i64), ("dst_stride_h", c_i64),
-                ("page_size", c_i32), ("n_pages_cap", c_i32), ("dev_lengths", c_vp)]
+                ("page_size", c_i32), ("n_pages_cap", c_i32), ("dev_lengths", c_vp), ("cents_prepared", c_vp)]
 
 
 class AttnDesc(ctypes.Structure):

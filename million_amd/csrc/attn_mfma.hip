@@ -1031,8 +1031,10 @@ bool attn_mfma_supported(const AttnParams &p) {
     return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
 }
 
-static bool g_mfma_no_pipe = false;
-void set_mfma_no_pipe(bool on) { g_mfma_no_pipe = on; }
+// A/B knob (million_set_force_generic 2 / 3): 0 = auto, 1 = grouped kernel only, 2 = double the splits when that
+// brings a split into the pipelined kernel's range (two rounds of workgroups per CU)
+static int g_mfma_policy = 0;
+void set_mfma_policy(int policy) { g_mfma_policy = policy; }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     AttnParams p = p_in;
@@ -1053,6 +1055,10 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     int len = p.T > 0 ? (p.T + ns - 1) / ns : 64;
     len = (len + 63) / 64 * 64;
     ns = p.T > 0 ? (p.T + len - 1) / len : 1;
+    if (g_mfma_policy == 2 && len > 40 * 32 && 2 * ns <= kMaxSplits) {
+        const int len2 = ((p.T + 2 * ns - 1) / (2 * ns) + 63) / 64 * 64;
+        if (len2 > 24 * 32 && len2 <= 40 * 32) { len = len2; ns = (p.T + len - 1) / len; }
+    }
     p.nsplit = ns;
     p.nslots = ns;
     p.split_len = len;
@@ -1064,7 +1070,7 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         attr_set = true;
     }
     // the pipelined kernel runs every wave through 4 units (+ a fifth where it exists): splits of 25..40 units
-    if (!g_mfma_no_pipe && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
+    if (g_mfma_policy != 1 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
         hipLaunchKernelGGL(attn_mfma_pipe_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else if (p.T > 0)
         hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);

@@ -209,6 +209,7 @@ __device__ __forceinline__ void publish_and_merge(const AttnParams &p, int b, in
 struct EncParams {
     const f16 *x;
     const f16 *cents;
+    const float *cents32;   // fp32 row image [m][c][dm] of a prepared codebook, or null
     uint8_t *dst;
     const int *page_ids;
     int bs, nh_k, n, d, M, C, dm;
@@ -228,5 +229,7 @@ bool attn_mfma_shape_ok(const AttnParams &p);
 int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hipStream_t s);
 bool attn_mfma_supported(const AttnParams &p);
 void set_error(const char *fmt, ...);
+
+void set_mfma_policy(int policy);   // attn_mfma.hip: A/B knob behind million_set_force_generic(2 / 3)
 
 }  // namespace million

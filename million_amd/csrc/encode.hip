@@ -9,26 +9,133 @@
 // acc = sq_0 + sq_1 + ... sequentially, every operation one IEEE fp32 round-to-nearest, no FMA
 // contraction; strict '<' scan over increasing c, so the lowest index wins exact ties.
 //
-// Mapping: wave = one subspace m, lane = one token.  The centroid row of m (C*d_m halfs) is wave-uniform
-// and comes through the scalar cache; the per-lane state is d_m fp32 values, the running best distance
-// and its index.
+// Mapping: a wave owns 4 consecutive subspaces of 64 tokens (lane = token): the lane's 4*d_m input halfs are
+// one vector load, the 4 code bytes of a token leave as one 32-bit store (row-major / K pages) or as four
+// lane-contiguous byte rows (transposed V pages).  The centroid row of a subspace is wave-uniform and comes
+// through the scalar cache as SGPR operands: from the fp32 image of a prepared codebook (million_prepare_cents)
+// the inner loop is, for d_m = 2, v_pk_add_f32 (x - c), v_pk_mul_f32, v_add_f32, v_cmp_lt_f32, v_cndmask (index),
+// v_min_f32 (distance): 6 vector instructions per centroid test; from the raw fp16 codebook two more
+// (v_cvt_f32_f16 of the centroid pair).  Packed fp32 operations round each half exactly like the scalar ones.
+//
+// Roofline: pure vector ALU.  32K tokens x 8 kv heads x 64 subspaces x 256 centroids = 4.3e9 tests per layer and
+// side; at 6 instructions per test and one 64-lane instruction per 4 cycles per SIMD (1024 SIMDs, ~2.4 GHz:
+// 39e12 lane-instructions/s) the floor is ~0.66 ms; HBM traffic (67 MB in, 17 MB out) is two orders below that.
 #include "common.h"
 
 #pragma clang fp contract(off)
 
 namespace million {
 
-
 constexpr int kEncBlock = 256;
+constexpr int kEncSub = 4;      // subspaces per wave
 
-template <int DM>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int DM, bool F32TAB>
 __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
     const int lane = threadIdx.x & 63;
-    const int m = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (kEncBlock / 64) + (threadIdx.x >> 6)));
+    const int mg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (kEncBlock / 64) + (threadIdx.x >> 6)));
+    const int m0 = mg * kEncSub;
+    const int bh = blockIdx.z;
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int t = blockIdx.x * 64 + lane;
+    if (m0 >= p.M) return;
+    const bool valid = t < p.n;
+    const int tc = valid ? t : p.n - 1;
+    int tok0 = p.tok0, xrow_start = p.xrow_start;
+    if (p.dev_lengths) { tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2]; }
+    const int xrow = p.xrow_mod > 0 ? (xrow_start + tc) % p.xrow_mod : tc;
+    const f16 *xp = p.x + b * p.xsb + hk * p.xsh + (long long)xrow * p.xsn + m0 * DM;
+    const int nsub = p.M - m0 < kEncSub ? p.M - m0 : kEncSub;      // wave-uniform
+    float x[kEncSub][DM];
+#pragma unroll
+    for (int j = 0; j < kEncSub; ++j)
+#pragma unroll
+        for (int k = 0; k < DM; ++k) x[j][k] = j < nsub ? (float)xp[j * DM + k] : 0.f;
+
+    unsigned codes = 0;
+#pragma unroll
+    for (int j = 0; j < kEncSub; ++j) {
+        if (j >= nsub) break;
+        const int m = m0 + j;
+        const float *__restrict__ c32 = p.cents32 + (long long)m * p.C * DM;   // wave-uniform rows
+        const f16 *__restrict__ c16 = p.cents + (long long)m * p.C * DM;
+        float best = INFINITY;
+        int best_c = 0;
+#pragma unroll 16
+        for (int c = 0; c < p.C; ++c) {
+            float cv[DM];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) cv[k] = F32TAB ? c32[c * DM + k] : (float)c16[c * DM + k];
+            float acc = 0.f;
+            if (DM % 2 == 0) {
+                // pairs of dims as packed fp32: every lane-half is one IEEE round-to-nearest operation
+#pragma unroll
+                for (int k = 0; k < DM; k += 2) {
+                    const v2f xv = {x[j][k], x[j][k + 1]}, cc = {cv[k], cv[k + 1]};
+                    const v2f e = xv - cc;
+                    const v2f sq = e * e;
+                    acc = (k == 0) ? sq[0] : acc + sq[0];
+                    acc = acc + sq[1];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < DM; ++k) {
+                    const float e = x[j][k] - cv[k];
+                    const float sq = e * e;
+                    acc = (k == 0) ? sq : acc + sq;
+                }
+            }
+            // strict '<', increasing c: the lowest index wins exact ties.  Written as "keep unless smaller" so that the
+            // select is (condition ? register : constant): v_cndmask takes the constant c as a literal, no v_mov
+            best_c = !(acc < best) ? best_c : c;
+            best = fminf(best, acc);
+        }
+        codes |= (unsigned)best_c << (8 * j);
+    }
+    if (!valid) return;
+    const int tok = tok0 + t;
+    if (p.layout == MILLION_CODES_VPAGES) {
+        const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
+        const int off = tok % p.page_size;
+#pragma unroll
+        for (int j = 0; j < kEncSub; ++j)
+            if (j < nsub) p.dst[(pid * p.M + m0 + j) * p.page_size + off] = (uint8_t)(codes >> (8 * j));
+        return;
+    }
+    uint8_t *row;
+    if (p.layout == MILLION_CODES_ROWMAJOR) {
+        row = p.dst + b * p.dsb + hk * p.dsh + (long long)tok * p.M + m0;
+    } else {
+        const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
+        row = p.dst + (pid * p.page_size + tok % p.page_size) * p.M + m0;
+    }
+    if (nsub == kEncSub && ((size_t)row & 3) == 0) {
+        *(unsigned *)row = codes;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kEncSub; ++j)
+            if (j < nsub) row[j] = (uint8_t)(codes >> (8 * j));
+    }
+}
+
+// Small calls (a flush of 64 window rows: 512 (row, subspace) pairs per kv head) cannot hide the scalar-cache
+// round trips of the kernel above behind other waves: 32 dependent s_load batches of ~0.6 us each.  This variant
+// puts the wave's centroid row into LDS with ONE vector round trip (converted to fp32 on the way) and reads it back
+// with wave-uniform (broadcast) ds_reads that pipeline; one subspace per wave for the most parallelism.
+template <int DM>
+__global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p) {
+    __shared__ float rows[kEncBlock / 64][256 * DM];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = blockIdx.y * (kEncBlock / 64) + w;
     const int bh = blockIdx.z;
     const int b = bh / p.nh_k, hk = bh % p.nh_k;
     const int t = blockIdx.x * 64 + lane;
     if (m >= p.M) return;
+    const f16 *cm = p.cents + (long long)m * p.C * DM;
+    float *row = rows[w];
+    for (int e = lane; e < p.C * DM; e += 64) row[e] = (float)cm[e];     // own region, own wave: LDS order suffices
     const bool valid = t < p.n;
     const int tc = valid ? t : p.n - 1;
     int tok0 = p.tok0, xrow_start = p.xrow_start;
@@ -38,19 +145,19 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
     float x[DM];
 #pragma unroll
     for (int k = 0; k < DM; ++k) x[k] = (float)xp[k];
-
-    const f16 *cm = p.cents + (long long)m * p.C * DM;   // wave-uniform
     float best = INFINITY;
     int best_c = 0;
+#pragma unroll 8
     for (int c = 0; c < p.C; ++c) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
-            const float e = x[k] - (float)cm[c * DM + k];
+            const float e = x[k] - row[c * DM + k];
             const float sq = e * e;
             acc = (k == 0) ? sq : acc + sq;
         }
-        if (acc < best) { best = acc; best_c = c; }
+        best_c = acc < best ? c : best_c;
+        best = fminf(best, acc);
     }
     if (!valid) return;
     const int tok = tok0 + t;
@@ -59,21 +166,33 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
     } else {
         const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
         const int off = tok % p.page_size;
-        if (p.layout == MILLION_CODES_KPAGES)
-            p.dst[(pid * p.page_size + off) * p.M + m] = (uint8_t)best_c;
-        else
-            p.dst[(pid * p.M + m) * p.page_size + off] = (uint8_t)best_c;
+        if (p.layout == MILLION_CODES_KPAGES) p.dst[(pid * p.page_size + off) * p.M + m] = (uint8_t)best_c;
+        else p.dst[(pid * p.M + m) * p.page_size + off] = (uint8_t)best_c;
     }
+}
+
+template <int DM>
+static void launch_dm(const EncParams &p, dim3 grid, hipStream_t s) {
+    // fewer than ~one wave per SIMD with 4 subspaces per wave: latency-bound, take the LDS variant
+    const long long waves4 = (long long)grid.x * grid.y * (kEncBlock / 64) * grid.z;
+    if (waves4 < 1024) {
+        dim3 g1(grid.x, (p.M + kEncBlock / 64 - 1) / (kEncBlock / 64), grid.z);
+        hipLaunchKernelGGL((pq_encode_small_kernel<DM>), g1, dim3(kEncBlock), 0, s, p);
+        return;
+    }
+    if (p.cents32) hipLaunchKernelGGL((pq_encode_kernel<DM, true>), grid, dim3(kEncBlock), 0, s, p);
+    else hipLaunchKernelGGL((pq_encode_kernel<DM, false>), grid, dim3(kEncBlock), 0, s, p);
 }
 
 int launch_encode(const EncParams &p, hipStream_t s) {
     if (p.n <= 0 || p.bs * p.nh_k <= 0) return MILLION_OK;
-    dim3 grid((p.n + 63) / 64, (p.M + kEncBlock / 64 - 1) / (kEncBlock / 64), p.bs * p.nh_k);
+    const int groups = (p.M + kEncSub - 1) / kEncSub;
+    dim3 grid((p.n + 63) / 64, (groups + kEncBlock / 64 - 1) / (kEncBlock / 64), p.bs * p.nh_k);
     switch (p.dm) {
-        case 1: hipLaunchKernelGGL(pq_encode_kernel<1>, grid, dim3(kEncBlock), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(pq_encode_kernel<2>, grid, dim3(kEncBlock), 0, s, p); break;
-        case 4: hipLaunchKernelGGL(pq_encode_kernel<4>, grid, dim3(kEncBlock), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(pq_encode_kernel<8>, grid, dim3(kEncBlock), 0, s, p); break;
+        case 1: launch_dm<1>(p, grid, s); break;
+        case 2: launch_dm<2>(p, grid, s); break;
+        case 4: launch_dm<4>(p, grid, s); break;
+        case 8: launch_dm<8>(p, grid, s); break;
         default: set_error("encode: d/M=%d unsupported (1,2,4,8)", p.dm); return MILLION_ERR_SHAPE;
     }
     const hipError_t e = hipGetLastError();

@@ -30,14 +30,16 @@ static int num_cus() {
     return n;
 }
 
-// ---- prepare_cents: (M, C, dm) -> row image [m][c][dm] followed by col image [c][m][dm] ----
+// ---- prepare_cents: (M, C, dm) -> fp16 row image [m][c][dm], fp16 col image [c][m][dm], fp32 row image ----
 __global__ void prepare_cents_kernel(const f16 *__restrict__ src, f16 *__restrict__ dst, int M, int C, int dm) {
     const int n = M * C * dm;
+    float *dst32 = (float *)(dst + 2 * (long long)n);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const f16 v = src[i];
         const int k = i % dm, c = (i / dm) % C, m = i / (dm * C);
         dst[i] = v;
         dst[n + ((long long)c * M + m) * dm + k] = v;
+        dst32[i] = (float)v;
     }
 }
 
@@ -173,13 +175,18 @@ extern "C" {
 
 int million_version(void) { return MILLION_HIP_VERSION; }
 const char *million_last_error(void) { return g_err; }
-void million_set_force_generic(int on) { g_force_generic = on; }
+void million_set_force_generic(int on) {
+    g_force_generic = (on == 1);
+    million::set_mfma_policy(on == 2 ? 1 : on == 3 ? 2 : 0);
+}
 void million_debug_set_stamp_buffer(void *buf) { g_dbg = (unsigned long long *)buf; }
 int million_debug_rows_reduce(const float *in64, float *out_max64, float *out_sum64, million_stream_t stream) {
     return launch_rows_reduce_check(in64, out_max64, out_sum64, (hipStream_t)stream);
 }
 
-size_t million_prepared_cents_bytes(int M, int C, int d_m) { return (size_t)2 * M * C * d_m * sizeof(f16); }
+size_t million_prepared_cents_bytes(int M, int C, int d_m) {
+    return (size_t)M * C * d_m * (2 * sizeof(f16) + sizeof(float));      // two fp16 images + the fp32 image
+}
 
 int million_prepare_cents(const void *cents, int M, int C, int d_m, void *prepared, million_stream_t stream) {
     if (!cents || !prepared) { set_error("prepare_cents: null pointer"); return MILLION_ERR_ARG; }
@@ -199,6 +206,8 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
     EncParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const f16 *)x; p.cents = (const f16 *)cents; p.dst = (uint8_t *)dst; p.page_ids = page_ids;
+    if (desc->cents_prepared)
+        p.cents32 = (const float *)((const f16 *)desc->cents_prepared + 2 * (size_t)desc->M * desc->C * (desc->d / (desc->M > 0 ? desc->M : 1)));
     p.bs = desc->bs; p.nh_k = desc->nh_k; p.n = desc->n; p.d = desc->d; p.M = desc->M; p.C = desc->C;
     if (p.bs <= 0 || p.nh_k <= 0 || p.n < 0) { set_error("encode: bs=%d nh_k=%d n=%d", p.bs, p.nh_k, p.n); return MILLION_ERR_SHAPE; }
     if (p.M <= 0 || p.d <= 0 || p.d % p.M) { set_error("encode: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }

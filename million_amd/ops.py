@@ -62,8 +62,10 @@ def prepare_cents(cents: torch.Tensor, cache: bool = True) -> torch.Tensor:
 def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, layout: int = L.MILLION_CODES_ROWMAJOR,
                    token_start: int = 0, n: Optional[int] = None, page_ids: Optional[torch.Tensor] = None,
                    page_size: int = 0, x_row_start: int = 0, x_row_mod: int = 0,
-                   dev_lengths: Optional[torch.Tensor] = None) -> None:
-    """Encode rows of X (bs, nh_k, n_rows, d) fp16 and write the codes into `dst` in their final layout."""
+                   dev_lengths: Optional[torch.Tensor] = None, use_prepared: bool = True) -> None:
+    """Encode rows of X (bs, nh_k, n_rows, d) fp16 and write the codes into `dst` in their final layout.
+    use_prepared: hand the kernel the (cached) prepared codebook, whose fp32 image makes the distance loop ~1.6x
+    faster; the codes are bit-identical either way."""
     _need_cuda(X, cents, dst, page_ids)
     if X.dtype != torch.float16 or cents.dtype != torch.float16 or dst.dtype != torch.uint8:
         raise RuntimeError("pq_encode: X and cents must be fp16, dst uint8")
@@ -92,6 +94,7 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
             raise RuntimeError("pq_encode: page pool must be contiguous")
         desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
     desc.dev_lengths = _ptr(dev_lengths)
+    desc.cents_prepared = prepare_cents(cents).data_ptr() if use_prepared else None
     lib = L.load()
     L.check(lib.million_pq_encode(ctypes.byref(desc), X.data_ptr(), cents.data_ptr(), dst.data_ptr(),
                                   _ptr(page_ids), _stream()), "million_pq_encode")
@@ -247,7 +250,9 @@ def lengths_advance(dev_lengths: torch.Tensor, n_flushed: int, resid_cap: int) -
                                              _stream()), "million_lengths_advance")
 
 
-def set_force_generic(on: bool) -> None:
+def set_force_generic(on) -> None:
+    """0 / False = auto, 1 / True = generic kernel only, 2 = grouped MFMA kernel only, 3 = prefer the pipelined MFMA
+    kernel (million_hip.h: million_set_force_generic)."""
     L.load().million_set_force_generic(int(on))
 
 

@@ -62,7 +62,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.million_attn_workspace_bytes(ctypes.byref(d)) > 8 * 65 * 4 * 130 * 4
     e = _lib.EncodeDesc()
     assert lib.million_pq_encode(ctypes.byref(e), None, None, None, None, None) == -3
-    assert lib.million_prepared_cents_bytes(64, 256, 2) == 2 * 64 * 256 * 2 * 2
+    assert lib.million_prepared_cents_bytes(64, 256, 2) == 64 * 256 * 2 * (2 * 2 + 4)   # two fp16 images + one fp32
 
 
 def test_bindings_exports_reference_names():

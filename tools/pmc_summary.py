@@ -19,7 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = ROOT / "gpurun_out"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
-KERNEL = "attn_mfma_kernel"
+KERNEL = "attn_mfma"        # the fused decode-attention launch: attn_mfma_pipe_kernel (headline shape) / attn_mfma_kernel
 
 summary = {"kernel": KERNEL, "tag": tag}
 ks = glob.glob(str(src / "prof_kt" / "*" / "*_kernel_stats.csv"))
@@ -31,10 +31,12 @@ if ks:
         w.writeheader()
         for r in keep:
             w.writerow(r)
-    for r in keep:
-        if KERNEL in r["Name"]:
-            summary["rocprof_avg_ns"] = float(r["AverageNs"])
-            summary["rocprof_calls"] = int(r["Calls"])
+    cand = [r for r in keep if KERNEL in r["Name"]]
+    if cand:
+        r = max(cand, key=lambda r: int(r["Calls"]))      # the variant the run actually used
+        summary["kernel"] = r["Name"].split("(")[0]
+        summary["rocprof_avg_ns"] = float(r["AverageNs"])
+        summary["rocprof_calls"] = int(r["Calls"])
 pmc = defaultdict(list)
 for d in ("prof_fetch", "prof_write", "prof_sq"):
     for f in glob.glob(str(src / d / "*" / "*_counter_collection.csv")):

@@ -20,12 +20,14 @@ ap.add_argument("--bs", type=int, default=1)
 ap.add_argument("--r", type=int, default=100)
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--grouped", action="store_true", help="labels of the grouped kernel")
+ap.add_argument("--policy", type=int, default=0, help="million_set_force_generic value (2 = grouped only, 3 = prefer pipelined)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 M, C, d, ps = 64, 256, 128, 64
 bs, nh, nhk, T = args.bs, args.nh, args.nhk, args.T
 n_pages = (T + ps - 1) // ps
 lib = L.load()
+lib.million_set_force_generic(args.policy)
 states = []
 for l in range(args.layers):
     kpool = torch.randint(0, 256, (bs * nhk * n_pages, ps, M), dtype=torch.uint8, device=dev)
