@@ -20,9 +20,12 @@
 //     the G heads, moved from the score layout with v_permlane32_swap / v_permlane16_swap;
 //   * online softmax per wave in the exp2 domain, fp32; wave partials are merged through LDS, split
 //     partials through the workspace by the last-arriving workgroup (common.h:publish_and_merge);
-//   * the residual window (r <= 128 fp16 rows) is dealt round-robin to the splits and goes through the
-//     same MFMA score path (A = the fp16 K rows themselves); its V rows are accumulated with fp32 FMAs.
-//     Its rows are requested first thing in the kernel and consumed while the code ring is in flight.
+//   * the residual window (r <= 128 fp16 rows) is dealt round-robin to the splits and, inside a split, to its
+//     waves: each wave's rows are ONE 16-row MFMA tile (scores: A = the fp16 K rows; values: B = the fp16 V rows)
+//     that rides along with the wave's code units - no separate partial, no scalar FMA loop.
+//   * two kernels share everything above and the merge tail: attn_mfma_kernel (groups of 4 units: score pass,
+//     softmax, value pass; any split length) and attn_mfma_pipe_kernel (splits of 25..40 units: value steps of
+//     unit u interleaved with the score stages of unit u + 1, online softmax per unit).
 #include "common.h"
 
 namespace million {
@@ -181,28 +184,39 @@ __device__ __forceinline__ void load_pids4(const AttnParams &p, int bh, const in
 }
 
 // Request the 16-byte loads of one 32-token unit (see UnitCodes): two for the K bytes, two for the V bytes.
-// t_unit: multiple of 32, < T.
+// t_unit: multiple of 32, < T, wave-uniform.  Addresses are a wave-uniform 64-bit base (scalar ALU, forced
+// into SGPRs) plus a 32-bit per-lane offset, so that the loads take the saddr + voffset form: the per-lane
+// 64-bit pointer arithmetic of the obvious formulation was ~10 vector instructions per request.
+typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;      // global address space: an integer -> pointer
+                                                                       // cast would otherwise make FLAT loads
+__device__ __forceinline__ gptr_u8 uniform_ptr(const uint8_t *q) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gptr_u8)(((unsigned long long)hi << 32) | lo);
+}
+typedef const __attribute__((address_space(1))) v4u *gptr_v4u;
 __device__ __forceinline__ void load_unit_k(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
                                             int lane, UnitCodes &u) {
     const int q4 = lane >> 4, c16 = lane & 15;
-    const int page0 = (t_unit >> p.ps_shift) << p.ps_shift;          // a unit never straddles a page
+    const int inpage = t_unit - ((t_unit >> p.ps_shift) << p.ps_shift);          // a unit never straddles a page
+    const gptr_u8 base = uniform_ptr(p.k_paged ? p.k_codes + (((pid.k << p.ps_shift) + inpage) << 6)
+                                                : p.k_codes + b * p.k_sb + hk * p.k_sh + ((long long)t_unit << 6));
+    const int lim = T - 1 - t_unit;                  // rows past token T-1 re-read it (stay inside the store; masked later)
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-        int tok = t_unit + 16 * g2 + c16;
-        tok = tok < T ? tok : T - 1;                 // stay inside the store; masked later
-        const uint8_t *src = p.k_paged
-            ? p.k_codes + (((pid.k << p.ps_shift) + (tok - page0)) << 6) + 16 * q4
-            : p.k_codes + b * p.k_sb + hk * p.k_sh + ((long long)tok << 6) + 16 * q4;
-        u.k[g2] = *(const v4u *)src;
+        const int row = min(16 * g2 + c16, lim);
+        const unsigned off = ((unsigned)row << 6) + 16u * q4;
+        u.k[g2] = *(gptr_v4u)(base + off);
     }
 }
 __device__ __forceinline__ void load_unit_v(const AttnParams &p, const PidPair &pid, int t_unit, int lane, UnitCodes &u) {
     const int h2i = lane >> 5, c32 = lane & 31;
     const int inpage = t_unit - ((t_unit >> p.ps_shift) << p.ps_shift);
+    const gptr_u8 base = uniform_ptr(p.v_codes + (pid.v << (6 + p.ps_shift)) + inpage);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const uint8_t *src = p.v_codes + (((pid.v << 6) + 32 * n + c32) << p.ps_shift) + inpage + 16 * h2i;
-        u.v[n] = *(const v4u *)src;
+        const unsigned off = ((unsigned)(32 * n + c32) << p.ps_shift) + 16u * h2i;      // loop-invariant per lane
+        u.v[n] = *(gptr_v4u)(base + off);
     }
 }
 __device__ __forceinline__ void load_unit_pid(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
