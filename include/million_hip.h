@@ -95,6 +95,15 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
                       void *dst, const int32_t *page_ids, million_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * PQ decode (reconstruction).
+ * Replaces: sa_decode_4d (scripts/utils/pq_utils.py:501-540): out[row, m*d_m + k] = cents[m, codes[row, m], k].
+ * codes: (n_rows, M) u8 contiguous (any leading dims flattened); cents: the RAW (M, C, d_m) fp16 codebook;
+ * out: (n_rows, d) fp16 contiguous.  Exact (a gather).  Used by the reference only in fallbacks and the
+ * perplexity path (pq_utils.py:198-204), so this is a plain bandwidth kernel with the codebook staged in LDS. */
+int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n_rows, int d, int M, int C,
+                      million_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused decode-step attention.
  * Replaces: flash_decoding_allocated_buffer<> (Interface.template.cu:26-120), i.e. the LUT matmul
  * (:49-50), flash_decoding_split_kernel (Kernel.cuh:11-166), flash_decoding_residual_kernel

@@ -42,6 +42,7 @@ SYMBOLS = {
     "million_prepared_cents_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "million_prepare_cents": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "million_pq_encode": (c_i32, [ctypes.POINTER(EncodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "million_pq_decode": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "million_attn_workspace_bytes": (c_sz, [ctypes.POINTER(AttnDesc)]),
     "million_workspace_init": (c_i32, [c_vp, c_sz, c_vp]),
     "million_pq_decode_attn": (c_i32, [ctypes.POINTER(AttnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

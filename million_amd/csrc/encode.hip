@@ -200,4 +200,42 @@ int launch_encode(const EncParams &p, hipStream_t s) {
     return MILLION_OK;
 }
 
+// ---- PQ decode: out[row, m*dm + k] = cents[m, codes[row, m], k] (sa_decode_4d, pq_utils.py:501-540) -------------
+// The codebook (<= 64 KiB) is staged in LDS once per workgroup; thread = (row, subspace): consecutive threads read
+// consecutive code bytes and write consecutive dm-half groups.  Grid-stride over row tiles.
+template <int DM>
+__global__ __launch_bounds__(256) void pq_decode_kernel(const uint8_t *__restrict__ codes, const f16 *__restrict__ cents,
+                                                        f16 *__restrict__ out, long long n_rows, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+    typedef struct { f16 v[DM]; } __attribute__((aligned(2 * DM))) Entry;
+    Entry *tab = (Entry *)dec_smem;
+    const int n_ent = M * C;
+    for (int i = threadIdx.x; i < n_ent; i += 256) tab[i] = ((const Entry *)cents)[i];
+    __syncthreads();
+    const long long total = n_rows * M;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx % M);
+        const unsigned c = codes[idx];
+        ((Entry *)out)[idx] = tab[m * C + (c < (unsigned)C ? c : 0u)];
+    }
+}
+
+int launch_decode(const uint8_t *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s) {
+    if (n_rows <= 0) return MILLION_OK;
+    const size_t lds = (size_t)M * C * dm * sizeof(f16);
+    if (lds > 64 * 1024) { set_error("decode: codebook of %zu bytes does not fit the 64 KiB LDS stage", lds); return MILLION_ERR_SHAPE; }
+    long long blocks = (n_rows * M + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    switch (dm) {
+        case 1: hipLaunchKernelGGL(pq_decode_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
+        case 2: hipLaunchKernelGGL(pq_decode_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
+        case 4: hipLaunchKernelGGL(pq_decode_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
+        case 8: hipLaunchKernelGGL(pq_decode_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
+        default: set_error("decode: d/M=%d unsupported (1,2,4,8)", dm); return MILLION_ERR_SHAPE;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("decode launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
 }  // namespace million

@@ -228,6 +228,15 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
     return launch_encode(p, (hipStream_t)stream);
 }
 
+int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n_rows, int d, int M, int C,
+                      million_stream_t stream) {
+    if (n_rows < 0 || M <= 0 || d <= 0 || d % M) { set_error("decode: n_rows=%lld d=%d M=%d", (long long)n_rows, d, M); return MILLION_ERR_SHAPE; }
+    if (C < 1 || C > 256) { set_error("decode: C=%d (uint8 codes)", C); return MILLION_ERR_SHAPE; }
+    if (n_rows == 0) return MILLION_OK;
+    if (!codes || !cents || !out) { set_error("decode: null pointer"); return MILLION_ERR_ARG; }
+    return launch_decode((const uint8_t *)codes, (const f16 *)cents, (f16 *)out, n_rows, M, C, d / M, (hipStream_t)stream);
+}
+
 size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
     if (!desc || desc->nh_k <= 0 || desc->nh % desc->nh_k) return 0;
     const int G = desc->nh / desc->nh_k;

@@ -100,6 +100,23 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
                                   _ptr(page_ids), _stream()), "million_pq_encode")
 
 
+def pq_decode(codes: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
+    """Drop-in for sa_decode_4d (reference pq_utils.py:501-540): codes (..., M) u8 + (M, C, d_m) fp16 codebook ->
+    (..., d) fp16 reconstruction (exact gather)."""
+    _need_cuda(codes, cents)
+    if codes.dtype != torch.uint8 or cents.dtype != torch.float16 or cents.dim() != 3:
+        raise RuntimeError("pq_decode: codes must be uint8 and cents fp16 (M, C, d_m)")
+    M, C, dm = cents.shape
+    if codes.shape[-1] != M:
+        raise RuntimeError(f"pq_decode: codes have {codes.shape[-1]} subspaces, codebook {M}")
+    codes, cents = codes.contiguous(), cents.contiguous()
+    out = torch.empty(*codes.shape[:-1], M * dm, dtype=torch.float16, device=codes.device)
+    n_rows = codes.numel() // M
+    L.check(L.load().million_pq_decode(codes.data_ptr(), cents.data_ptr(), out.data_ptr(), n_rows, M * dm, M, C,
+                                       _stream()), "million_pq_decode")
+    return out
+
+
 def pq_encode(X: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
     """Drop-in for sa_encode_4d_keops (reference pq_utils.py:451-499): (bs, nh_k, n, d) -> (bs, nh_k, n, M) u8."""
     bs, nhk, n, d = X.shape

@@ -454,3 +454,18 @@ def test_fused_append_long_context_device_lengths(env, oracle):
         c2 = dict(c, k_codes=c["k_codes"][:, :, :T], v_codes=c["v_codes"][:, :, :T], k_res=k_hist, v_res=v_hist, r=r + 1)
         _check(out.cpu().numpy(), oracle.decode_attn(**c2), f"T={T} r={r}")
         assert lengths.cpu().numpy()[:, 1].tolist() == [r + 1] * bs
+
+
+@pytest.mark.parametrize("shape,M,C,dm", [((2, 3, 257), 64, 256, 2), ((1, 8, 4096), 32, 256, 4), ((5,), 16, 128, 4),
+                                          ((1, 1, 0), 64, 256, 2), ((7, 33), 16, 256, 8)])
+def test_pq_decode_exact(shape, M, C, dm, env, oracle):
+    """million_pq_decode = sa_decode_4d (pq_utils.py:501-540): an exact gather, compared with the oracle's."""
+    torch, ops = env
+    rs = np.random.RandomState(M + dm)
+    codes = rs.randint(0, C, size=shape + (M,)).astype(np.uint8)
+    cents = rs.standard_normal((M, C, dm)).astype(np.float16)
+    out = ops.pq_decode(torch.from_numpy(codes).cuda(), torch.from_numpy(cents).cuda())
+    torch.cuda.synchronize()
+    gold = oracle.pq_decode_numpy(codes.reshape(1, 1, -1, M), cents).reshape(shape + (M * dm,))
+    assert out.shape == gold.shape and out.dtype == torch.float16
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), gold.astype(np.float16).view(np.uint16))

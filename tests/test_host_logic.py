@@ -125,3 +125,49 @@ def test_harness_fp16_backends_agree_cpu():
     x = torch.arange(2 * 2 * 3 * 1, dtype=torch.float32).view(2, 2, 3, 1)
     r = H.repeat_kv(x, 2)
     assert r.shape == (2, 4, 3, 1) and torch.equal(r[:, 1], x[:, 0]) and torch.equal(r[:, 2], x[:, 1])
+
+
+def test_fvecs_and_centroid_formats(tmp_path):
+    """million_amd/formats.py against the byte layout the reference writes (fvecio.py:23-43; main_pq.py:222-260)."""
+    import struct
+    import numpy as np
+    from million_amd import formats as F
+    rs = np.random.RandomState(3)
+    a, b = rs.standard_normal((5, 128)).astype(np.float32), rs.standard_normal((3, 128)).astype(np.float32)
+    fn = tmp_path / "key_sampled_64_8.fvecs"
+    # hand-built bytes in the reference's record format: int32 d, then d float32, per vector
+    with open(fn, "wb") as f:
+        for v in a:
+            f.write(struct.pack("<i", 128) + v.tobytes())
+    np.testing.assert_array_equal(F.read_fvecs(fn), a)
+    F.write_fvecs(fn, b)                                   # default mode appends
+    np.testing.assert_array_equal(F.read_fvecs(fn), np.concatenate([a, b]))
+    with open(fn, "rb") as f:                               # and our writer produces those same bytes
+        blob = f.read()
+    assert blob[5 * 516: 5 * 516 + 4] == struct.pack("<i", 128) and blob[5 * 516 + 4: 6 * 516] == b[0].tobytes()
+    fn2 = tmp_path / "new.fvecs"
+    F.write_fvecs(fn2, a[0])                                # 1-D input = one vector; 'ab' on a missing file creates it
+    assert F.read_fvecs(fn2).shape == (1, 128)
+    with open(fn2, "ab") as f:
+        f.write(struct.pack("<i", 64) + b"\0" * 256)
+    with pytest.raises(ValueError):
+        F.read_fvecs(fn2)
+    (tmp_path / "empty.fvecs").write_bytes(b"")
+    assert F.read_fvecs(tmp_path / "empty.fvecs").shape == (0, 0)
+
+    kc, vc = torch.randn(64, 256, 2), torch.randn(64, 256, 2)
+    kp, vp = F.save_centroids(tmp_path / "cents", kc, vc, nbits=8)
+    assert kp.name == "key_cent_64_8.pq.pt" and vp.name == "val_cent_64_8.pq.pt"
+    assert torch.equal(torch.load(kp, weights_only=True), kc)          # what the reference's loader would see
+    k2, v2 = F.load_centroids(tmp_path / "cents", 64, 8, d=128)
+    assert k2.dtype == torch.float16 and torch.equal(k2, kc.half()) and torch.equal(v2, vc.half())
+    with pytest.raises(FileNotFoundError):
+        F.load_centroids(tmp_path / "cents", 32, 8)
+    with pytest.raises(ValueError):
+        F.load_centroid_file(kp, M=32)
+    with pytest.raises(ValueError):
+        F.load_centroid_file(kp, nbits=7)
+    torch.save({"not": "a tensor"}, tmp_path / "cents" / "key_cent_16_8.pq.pt")
+    torch.save(vc, tmp_path / "cents" / "val_cent_16_8.pq.pt")
+    with pytest.raises(ValueError):
+        F.load_centroids(tmp_path / "cents", 16, 8)
