@@ -26,6 +26,8 @@
 //   * two kernels share everything above and the merge tail: attn_mfma_kernel (groups of 4 units: score pass,
 //     softmax, value pass; any split length) and attn_mfma_pipe_kernel (splits of 25..40 units: value steps of
 //     unit u interleaved with the score stages of unit u + 1, online softmax per unit).
+#include <type_traits>
+
 #include "common.h"
 
 namespace million {
@@ -52,10 +54,19 @@ struct UnitCodes {
     v4u v[2];   // V code bytes: half n (32 subspaces), lane (h, c): m = 32n + c, tokens [16h, 16h+16)
 };
 
+// M = 32 (d_m = 4): a token's code row is 32 bytes, a codebook entry 8 bytes (one ds_read_b64)
+struct UnitCodes32 {
+    v2u k[2];   // K code bytes: group g2 (16 tokens), lane (q, c): token c, bytes [8q, 8q+8)
+    v4u v[1];   // V code bytes: lane (h, c): subspace m = c, tokens [16h, 16h+16)
+};
+
 // LDS by absolute byte address: the dynamic LDS segment of this kernel starts at 0 (no static LDS; the
 // kernel traps otherwise), so a lookup address needs no base add.
 __device__ __forceinline__ unsigned lds32(unsigned addr) {
     return *(const __attribute__((address_space(3))) unsigned *)(size_t)addr;
+}
+__device__ __forceinline__ v2u lds64(unsigned addr) {
+    return *(const __attribute__((address_space(3))) v2u *)(size_t)addr;
 }
 // Diagnostic stamps go to LDS (lane 0 of each wave) and are copied out at the very end of the kernel: a global
 // store per stamp would put a vmcnt(0) into the phases being timed (and a generic-pointer store a FLAT op,
@@ -219,13 +230,37 @@ __device__ __forceinline__ void load_unit_v(const AttnParams &p, const PidPair &
         u.v[n] = *(gptr_v4u)(base + off);
     }
 }
+typedef const __attribute__((address_space(1))) v2u *gptr_v2u;
+__device__ __forceinline__ void load_unit_k(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
+                                            int lane, UnitCodes32 &u) {
+    const int q4 = lane >> 4, c16 = lane & 15;
+    const int inpage = t_unit - ((t_unit >> p.ps_shift) << p.ps_shift);
+    const gptr_u8 base = uniform_ptr(p.k_paged ? p.k_codes + (((pid.k << p.ps_shift) + inpage) << 5)
+                                               : p.k_codes + b * p.k_sb + hk * p.k_sh + ((long long)t_unit << 5));
+    const int lim = T - 1 - t_unit;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        const int row = min(16 * g2 + c16, lim);
+        const unsigned off = ((unsigned)row << 5) + 8u * q4;
+        u.k[g2] = *(gptr_v2u)(base + off);
+    }
+}
+__device__ __forceinline__ void load_unit_v(const AttnParams &p, const PidPair &pid, int t_unit, int lane, UnitCodes32 &u) {
+    const int h2i = lane >> 5, c32 = lane & 31;
+    const int inpage = t_unit - ((t_unit >> p.ps_shift) << p.ps_shift);
+    const gptr_u8 base = uniform_ptr(p.v_codes + (pid.v << (5 + p.ps_shift)) + inpage);
+    const unsigned off = ((unsigned)c32 << p.ps_shift) + 16u * h2i;
+    u.v[0] = *(gptr_v4u)(base + off);
+}
+template <class Unit>
 __device__ __forceinline__ void load_unit_pid(const AttnParams &p, int b, int hk, const PidPair &pid, int t_unit, int T,
-                                              int lane, UnitCodes &u) {
+                                              int lane, Unit &u) {
     load_unit_k(p, b, hk, pid, t_unit, T, lane, u);
     load_unit_v(p, pid, t_unit, lane, u);
 }
+template <class Unit>
 __device__ __forceinline__ void load_unit(const AttnParams &p, int b, int hk, int bh, int t_unit, int T,
-                                          int lane, UnitCodes &u) {
+                                          int lane, Unit &u) {
     load_unit_pid(p, b, hk, load_pids(p, bh, t_unit >> p.ps_shift), t_unit, T, lane, u);
 }
 
@@ -331,6 +366,100 @@ __device__ __forceinline__ void value_unit(const v4u (&vc)[2], const float (&pr)
 #undef V_GATHER
 }
 
+// ---- M = 32 forms of the two unit functions ------------------------------------------------------------
+// Scores: lane (q4, token) holds 8 code bytes = subspaces 8*q4 .. 8*q4+7; step s uses subspaces 8*q4 + 2s, +1 =
+// dims 32*q4 + 8s .. +8 (the SAME dim <-> k mapping as M = 64, so the query operand qb is shared); two 8-byte
+// gathers per step.
+__device__ __forceinline__ void k_gather32(unsigned w, int s, unsigned base, unsigned (&a)[4]) {
+    const unsigned sh = 16 * (s & 1);
+    const v2u lo = lds64(base + 0 * 2048 + (((w >> sh) & 0xffu) << 3));
+    const v2u hi = lds64(base + 1 * 2048 + (((w >> (sh + 8)) & 0xffu) << 3));
+    a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
+}
+template <bool MASK>
+__device__ __forceinline__ void score_unit(const v2u (&kc)[2], const v8f16 (&qb)[4], int t_unit, int t_end,
+                                           float scale_log2e, int lane, unsigned kbase, float (&sc)[8]) {
+    const int q4 = lane >> 4;
+    constexpr int kDepth = 3;
+    unsigned a[8][4];
+#pragma unroll
+    for (int st = 0; st < kDepth; ++st) k_gather32(kc[st >> 2][(st & 3) >> 1], st & 3, kbase + (st & 3) * 4096, a[st]);
+    v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        if (st + kDepth < 8) {
+            const int t = st + kDepth;
+            k_gather32(kc[t >> 2][(t & 3) >> 1], t & 3, kbase + (t & 3) * 4096, a[t]);
+        }
+        D[st >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(a[st][0], a[st][1], a[st][2], a[st][3]), qb[st & 3],
+                                                            D[st >> 2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const float v = D[g2][rho] * scale_log2e;
+            if (MASK) {
+                const int tok = t_unit + 16 * g2 + 4 * q4 + rho;
+                sc[g2 * 4 + rho] = tok < t_end ? v : -INFINITY;
+            } else {
+                sc[g2 * 4 + rho] = v;
+            }
+        }
+}
+// Values: lane (h, m): 16 token bytes of subspace m; an 8-byte gather brings the 4 dims of one (token, m); tile
+// O[i][j] holds dim 4m + 2i + j of the 32 subspaces (cols).  2 steps of 8 gathers + 16 packs + 4 MFMAs.
+__device__ __forceinline__ void value_unit(const v4u (&vc)[1], const float (&pr)[8], unsigned vconst0, unsigned /*vconst1*/,
+                                           v16f32 (&O)[2][2]) {
+    unsigned pk[2][2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            h2 t = {(f16)pr[g2 * 4 + 2 * i], (f16)pr[g2 * 4 + 2 * i + 1]};
+            pk[g2][i] = __builtin_bit_cast(unsigned, t);
+        }
+    unsigned P[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const v2u x = __builtin_amdgcn_permlane32_swap(pk[0][i], pk[1][i], false, false);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const v2u y = swap16_self(x[s]);
+            P[s][i] = y[0];
+            P[s][2 + i] = y[1];
+        }
+    }
+    unsigned e[2][2][8];      // [step][dword of the entry][token]
+#define V_GATHER32(ST)                                                                                             \
+    {                                                                                                              \
+        const unsigned w0 = vc[0][2 * (ST)], w1 = vc[0][2 * (ST) + 1];                                             \
+        const unsigned sel[4] = {0x03020400u, 0x03020500u, 0x03020600u, 0x03020700u};                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
+            const v2u t = lds64(__builtin_amdgcn_perm(j < 4 ? w0 : w1, vconst0, sel[j & 3]));                      \
+            e[ST][0][j] = t[0];                                                                                    \
+            e[ST][1][j] = t[1];                                                                                    \
+        }                                                                                                          \
+    }
+    V_GATHER32(0)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        if (st == 0) V_GATHER32(1)
+        const v8f16 A = as_v8f16(P[st][0], P[st][1], P[st][2], P[st][3]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned(&x)[8] = e[st][i];
+            const v8f16 B0 = as_v8f16(__builtin_amdgcn_perm(x[1], x[0], 0x05040100u), __builtin_amdgcn_perm(x[3], x[2], 0x05040100u),
+                                      __builtin_amdgcn_perm(x[5], x[4], 0x05040100u), __builtin_amdgcn_perm(x[7], x[6], 0x05040100u));
+            const v8f16 B1 = as_v8f16(__builtin_amdgcn_perm(x[1], x[0], 0x07060302u), __builtin_amdgcn_perm(x[3], x[2], 0x07060302u),
+                                      __builtin_amdgcn_perm(x[5], x[4], 0x07060302u), __builtin_amdgcn_perm(x[7], x[6], 0x07060302u));
+            O[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B0, O[i][0], 0, 0, 0);
+            O[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B1, O[i][1], 0, 0, 0);
+        }
+    }
+#undef V_GATHER32
+}
+
 // ---- residual window -------------------------------------------------------------------------------
 // The window rows j = split, split + nsplit, ... < r of a split are dealt to its waves round-robin: wave w
 // owns list entries idx = w + 8*i, i < kResRows, as ONE 16-row MFMA tile that rides along with the code
@@ -353,6 +482,7 @@ __device__ __forceinline__ long long res_row_off(const AttnParams &p, int idx, i
     return (long long)row * 128;
 }
 
+template <int MS = 64>
 __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const f16 *kr, const f16 *vr, int wave, int rcnt,
                                               int split, int rstart, int r_old, int lane, ResTile &t) {
     const int q4 = lane >> 4, c16 = lane & 15, h = lane >> 5, c32 = lane & 31;
@@ -367,9 +497,16 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
     for (int j = 0; j < 8; ++j) {
         bool is_new;
         const long long off = res_row_off(p, wave + kNW * (8 * h + j), wave, rcnt, split, rstart, r_old, is_new);
-        const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 2 * c32;
-        t.v[0][j] = *(const unsigned *)vp;
-        t.v[1][j] = *(const unsigned *)(vp + 64);
+        if (MS == 64) {      // tile (n, kk): dim 2*(32n + c32) + kk
+            const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 2 * c32;
+            t.v[0][j] = *(const unsigned *)vp;
+            t.v[1][j] = *(const unsigned *)(vp + 64);
+        } else {             // M = 32, tile (i, jj): dim 4*c32 + 2i + jj
+            const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 4 * c32;
+            const v2u w = *(const v2u *)vp;
+            t.v[0][j] = w[0];
+            t.v[1][j] = w[1];
+        }
     }
 }
 
@@ -407,6 +544,7 @@ __device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&p
 
 // ---- tail shared by the MFMA kernels: merge the waves of the workgroup through LDS (the tables are dead after
 //      the first barrier), publish the split's partial, merge the splits in the last-arriving workgroup ----
+template <int MS = 64>
 __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *smem, int b, int hk, int split, int G, int tid,
                                                   int lane, int wave, bool dbg_on, v16f32 (&O)[2][2], float m_run, float l_run) {
 #define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
@@ -427,7 +565,8 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) mine[g * 128 + 2 * (32 * n + c32) + kk] = O[n][kk][rho];
+                    for (int kk = 0; kk < 2; ++kk)
+                        mine[g * 128 + (MS == 64 ? 2 * (32 * n + c32) + kk : 4 * c32 + 2 * n + kk)] = O[n][kk][rho];
             }
         }
         if (lane < G) {                                  // lane g: row q' = 0, col g
@@ -476,8 +615,9 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
 #undef STAMP
 }
 
-template <bool HAS_CODES>
+template <bool HAS_CODES, int MS = 64>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
+    typedef typename std::conditional<MS == 64, UnitCodes, UnitCodes32>::type Unit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -550,10 +690,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
     ResTile rt;
-    if (has_res) load_res_tile(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+    if (has_res) load_res_tile<MS>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
 
     // ---- the K bytes of the whole ring, then the K codebook goes to LDS ----
-    UnitCodes ring[kRing];
+    Unit ring[kRing];
     PidPair pid4[kRing];
     if (HAS_CODES) {
         int pg[kRing];
@@ -605,8 +745,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     STAMP(2);
 
     const unsigned kbase = (unsigned)q4 * 16u * 1024u;                 // K row image: m = 16*q4 + ...
-    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);        // m = c
-    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);  // m = 32 + c
+    // V col image: entry (c, m) at c*256 + m*(2*d_m); the code byte goes to address bits 8..15 by v_perm
+    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3));        // m = c
+    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);  // m = 32 + c (M = 64 only)
 
     // ---- groups of kRing units: SCORE pass for the whole group (K codebook only), one softmax update per
     //      group, then the VALUE pass.  The first group also carries this wave's residual tile, and the V
@@ -694,7 +835,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #undef ISSUE_AFTER_UNIT
 #undef UNIT_T
     STAMP(3);
-    merge_and_publish(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
+    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
 #undef STAMP
 }
 
@@ -1038,7 +1179,7 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 
 // rcap <= kNW * kResRows: every window row of a split has a slot in some wave's residual tile
 bool attn_mfma_shape_ok(const AttnParams &p) {
-    return p.d == 128 && p.M == 64 && p.C == 256 && p.G <= kMaxG && p.rcap <= kNW * kResRows;
+    return p.d == 128 && (p.M == 64 || p.M == 32) && p.C == 256 && p.G <= kMaxG && p.rcap <= kNW * kResRows;
 }
 
 bool attn_mfma_supported(const AttnParams &p) {
@@ -1080,11 +1221,16 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         attr_set = true;
     }
-    // the pipelined kernel runs every wave through 4 units (+ a fifth where it exists): splits of 25..40 units
-    if (g_mfma_policy != 1 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
+    // the pipelined kernel (M = 64) runs every wave through 4 units (+ a fifth where it exists): splits of 25..40 units
+    if (p.M == 32) {
+        if (p.T > 0) hipLaunchKernelGGL((attn_mfma_kernel<true, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+        else hipLaunchKernelGGL((attn_mfma_kernel<false, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+    } else if (g_mfma_policy != 1 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
         hipLaunchKernelGGL(attn_mfma_pipe_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else if (p.T > 0)
         hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);

@@ -4,6 +4,7 @@ Bars (BASELINE.md 2 / SURVEY.md 8c): uint8 codes bit-exact with oracle/pq_oracle
 fp16 attention output within 1e-3 relative (rel-L2) and mean-abs < 1e-3 (the reference's own bar,
 scripts/utils/pq_utils.py:374-379) of the fp64 oracle.  Nothing here reads /root/reference.
 """
+import ctypes
 import hashlib
 import json
 
@@ -469,3 +470,22 @@ def test_pq_decode_exact(shape, M, C, dm, env, oracle):
     gold = oracle.pq_decode_numpy(codes.reshape(1, 1, -1, M), cents).reshape(shape + (M * dm,))
     assert out.shape == gold.shape and out.dtype == torch.float16
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), gold.astype(np.float16).view(np.uint16))
+
+
+# ---- M = 32 (d_m = 4, BASELINE configs[4]) on the MFMA kernel ---------------------------------------------------
+@pytest.mark.parametrize("T,r,nh,nhk,bs", [(257, 17, 8, 2, 1), (4096, 128, 32, 8, 1), (5000, 1, 8, 8, 2), (33, 0, 64, 8, 1),
+                                           (0, 77, 32, 8, 1), (65536 + 40, 100, 32, 8, 1)])
+def test_attn_m32_mfma(T, r, nh, nhk, bs, env, oracle):
+    torch, ops = env
+    from million_amd import _lib
+    c = synth.attn_case(7000 + T % 991 + r, bs, nh, nhk, 128, 32, 256, T, r)
+    gold = oracle.decode_attn(**c)
+    _check(_run_rowmajor(torch, ops, c, 32, 256), gold, "M=32 rowmajor (transpose + MFMA)")
+    if T:
+        _check(_run_paged(torch, ops, oracle, c, 32, 256, 64), gold, "M=32 paged")
+        _check(_run_paged(torch, ops, oracle, c, 32, 256, 32, k_paged=False, i64=True), gold, "M=32 mixed ps=32")
+    # and it really is the MFMA path
+    t = _dev(torch, c)
+    desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=32, C=256, n_tokens=max(T, 1), r=r, k_paged=True, v_paged=True,
+                              page_size=64, n_pages_cap=(max(T, 1) + 63) // 64)
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
