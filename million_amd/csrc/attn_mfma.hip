@@ -931,6 +931,40 @@ __device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, flo
     m_run = m_new;
 }
 
+// same on RAW scores (q.k, masked to -inf where needed): the 1/sqrt(d)*log2(e) factor c > 0 is folded into the exp2
+// argument (one fma per score instead of a multiply and a subtract), the running maximum stays in the scaled domain
+template <int N>
+__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float &m_run, float &l_run, v16f32 (&O)[2][2],
+                                                   int G, int lane) {
+    float mx = sc[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) mx = fmaxf(mx, sc[i]);
+    mx = rows_max(mx) * c;
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+    const float alpha = fast_exp2(m_run - m_safe);
+    if (__any(m_new > m_run && m_run > -INFINITY)) {
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
+            const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;
+            const float f = lane < 32 ? flo : fhi;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
+        }
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sc[i] = fast_exp2(fmaf(sc[i], c, -m_safe));
+        ls += sc[i];
+    }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+}
+
 template <bool HAS_CODES>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1063,12 +1097,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
         as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
 #define VG(SL, I) v_gather(ring[SL].v, I, vconst0, vconst1, e[(I) & 1])
 #define VS(I) v_step(e[(I) & 1], P[(I) & 1], O[(I) >> 1])
+    /* raw scores out of the accumulators; only a unit that reaches past the split's end (wave-uniform) is masked */  \
 #define SCORES_OUT(u)                                                                                              \
-    _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                               \
-        _Pragma("unroll") for (int rho = 0; rho < 4; ++rho) {                                                      \
-            const int tok = t_begin + 32 * (wave + (u) * kNW) + 16 * g2 + 4 * q4 + rho;                             \
-            sc[g2 * 4 + rho] = tok < t_end ? D[g2][rho] * p.scale_log2e : -INFINITY;                               \
-        }
+    {                                                                                                              \
+        const int t_u = t_begin + 32 * (wave + (u) * kNW);                                                         \
+        if (t_u + 32 <= t_end) {                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[i] = D[i >> 2][i & 3];                                \
+        } else {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+                sc[i] = t_u + 16 * (i >> 2) + 4 * q4 + (i & 3) < t_end ? D[i >> 2][i & 3] : -INFINITY;             \
+        }                                                                                                          \
+    }
 #define BLOCK(U4, u, LOADS)                                                                                        \
     {                                                                                                              \
         v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
@@ -1087,7 +1126,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
         KG(((U4) + 2) & 3, 1);                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         SCORES_OUT((u) + 1)                                                                                        \
-        softmax_online<8>(sc, m_run, l_run, O, G, lane);                                                           \
+        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
         value_prep(sc, P);                                                                                         \
     }
 #define VALUE_ALONE(U4)                                                                                            \
@@ -1123,7 +1162,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
             }
             SCORES_OUT(0)
         }
-        softmax_online<8>(sc, m_run, l_run, O, G, lane);
+        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);
         value_prep(sc, P);
         STAMP(16);
         {
