@@ -231,10 +231,33 @@ class DynamicPQCache(_CacheBase):
         self._T[layer_idx] = T + n
 
     def prefill(self, query_states, key_states, value_states, layer_idx, distort_recent=False):
+        """distort_recent=True attends to the DEQUANTISED prompt (perplexity-style evaluation of the quantiser,
+        pq_utils.py:222-260 docstring); leave it False when serving."""
         n = key_states.size(2)
+        T0 = self._T[layer_idx]
         self._append_codes((key_states, value_states), layer_idx, n)       # pq_utils.py:235-240
         self.seen_tokens[layer_idx] += n
+        if distort_recent:                                                 # :242-246
+            key_states = ops.pq_decode(self._k_store[layer_idx][:, :, T0:T0 + n], self.key_cent)
+            value_states = ops.pq_decode(self._v_store[layer_idx][:, :, T0:T0 + n], self.value_cent)
         return self._prefill_attention(query_states, key_states, value_states)
+
+    def update(self, key_states, value_states, layer_idx, distort_recent=False):
+        """The reference's non-kernel path (pq_utils.py:166-220), DynamicCache-compatible: encode and store the new
+        K/V, return the full-length fp16 K/V for a dense attention — the dequantised past followed by the new rows
+        as they are (or dequantised too with distort_recent).  No residual window on this path (as in the reference)."""
+        n = key_states.size(2)
+        T0 = self._T[layer_idx]
+        self._append_codes((key_states, value_states), layer_idx, n)
+        self.seen_tokens[layer_idx] += n
+        upto = T0 + n if distort_recent else T0
+        past_k = ops.pq_decode(self._k_store[layer_idx][:, :, :upto], self.key_cent) if upto else None
+        past_v = ops.pq_decode(self._v_store[layer_idx][:, :, :upto], self.value_cent) if upto else None
+        if distort_recent:
+            return past_k, past_v
+        if past_k is None:
+            return key_states, value_states
+        return torch.cat([past_k, key_states.to(past_k.dtype)], dim=2), torch.cat([past_v, value_states.to(past_v.dtype)], dim=2)
 
     def decoding(self, query_states, key_states, value_states, layer_idx):
         Lt = self.max_residual_length

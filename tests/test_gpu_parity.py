@@ -489,3 +489,40 @@ def test_attn_m32_mfma(T, r, nh, nhk, bs, env, oracle):
     desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=32, C=256, n_tokens=max(T, 1), r=r, k_paged=True, v_paged=True,
                               page_size=64, n_pages_cap=(max(T, 1) + 63) // 64)
     assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
+
+
+def test_dynamic_cache_update_and_distort_recent(env, oracle):
+    """DynamicPQCache.update / prefill(distort_recent=True): the reference's dequantise-then-attend path
+    (pq_utils.py:166-260) on the HIP encode + decode kernels, against the oracle's encode/decode."""
+    torch, ops = env
+    from million_amd.pq_cache import DynamicPQCache
+    bs, nh, nhk, M, d = 2, 8, 2, 64, 128
+    rs = np.random.RandomState(31)
+    cents_k = rs.standard_normal((M, 256, d // M)).astype(np.float16)
+    cents_v = rs.standard_normal((M, 256, d // M)).astype(np.float16)
+    cache = DynamicPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, max_tokens=512)
+    cache.set_cent(torch.from_numpy(cents_k).cuda(), torch.from_numpy(cents_v).cuda())
+    k1, v1 = rs.standard_normal((bs, nhk, 70, d)).astype(np.float16), rs.standard_normal((bs, nhk, 70, d)).astype(np.float16)
+    k2, v2 = rs.standard_normal((bs, nhk, 3, d)).astype(np.float16), rs.standard_normal((bs, nhk, 3, d)).astype(np.float16)
+    dq = lambda x, c: oracle.pq_decode_numpy(oracle.pq_encode(x, c), c)
+    # first update: nothing stored yet -> the inputs come back unchanged
+    K, V = cache.update(torch.from_numpy(k1).cuda(), torch.from_numpy(v1).cuda(), 0)
+    np.testing.assert_array_equal(K.cpu().numpy(), k1)
+    # second update: dequantised past ++ raw new rows
+    K, V = cache.update(torch.from_numpy(k2).cuda(), torch.from_numpy(v2).cuda(), 0)
+    np.testing.assert_array_equal(K.cpu().numpy(), np.concatenate([dq(k1, cents_k), k2], axis=2))
+    np.testing.assert_array_equal(V.cpu().numpy(), np.concatenate([dq(v1, cents_v), v2], axis=2))
+    assert cache.key_cache[0].shape == (bs, nhk, 73, M) and cache.seen_tokens[0] == 73
+    # distort_recent: everything dequantised, the new rows too
+    k3, v3 = rs.standard_normal((bs, nhk, 2, d)).astype(np.float16), rs.standard_normal((bs, nhk, 2, d)).astype(np.float16)
+    K, V = cache.update(torch.from_numpy(k3).cuda(), torch.from_numpy(v3).cuda(), 0, distort_recent=True)
+    np.testing.assert_array_equal(V.cpu().numpy(), np.concatenate([dq(v1, cents_v), dq(v2, cents_v), dq(v3, cents_v)], axis=2))
+    # prefill(distort_recent=True) == causal SDPA over the dequantised prompt
+    cache2 = DynamicPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, max_tokens=512)
+    cache2.set_cent(torch.from_numpy(cents_k).cuda(), torch.from_numpy(cents_v).cuda())
+    q = rs.standard_normal((bs, nh, 70, d)).astype(np.float16)
+    out = cache2.prefill(torch.from_numpy(q).cuda(), torch.from_numpy(k1).cuda(), torch.from_numpy(v1).cuda(), 0, distort_recent=True)
+    kd = torch.from_numpy(dq(k1, cents_k)).float().repeat_interleave(nh // nhk, dim=1)
+    vd = torch.from_numpy(dq(v1, cents_v)).float().repeat_interleave(nh // nhk, dim=1)
+    ref = torch.nn.functional.scaled_dot_product_attention(torch.from_numpy(q).float(), kd, vd, is_causal=True)
+    _check(out.float().cpu().numpy(), ref.numpy(), "prefill distort_recent")
