@@ -67,6 +67,10 @@ def load() -> ctypes.CDLL:
         if not LIB_PATH.exists():
             raise ImportError(f"{LIB_PATH} is missing: run `make bindings` (hipcc --offload-arch=gfx950). "
                               "There is no CPU fallback for the PQ-KV hot path.")
+        # torch first: its bundled HIP runtime must be the one this library binds to.  Loaded the other way round
+        # (this library pulling in the system libamdhip64 before torch brings its own) the process ends up with two
+        # runtimes and the second one reports "no ROCm-capable device".
+        import torch  # noqa: F401
         L = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)      # AttributeError if the ABI drifted

@@ -526,3 +526,42 @@ def test_dynamic_cache_update_and_distort_recent(env, oracle):
     vd = torch.from_numpy(dq(v1, cents_v)).float().repeat_interleave(nh // nhk, dim=1)
     ref = torch.nn.functional.scaled_dot_product_attention(torch.from_numpy(q).float(), kd, vd, is_causal=True)
     _check(out.float().cpu().numpy(), ref.numpy(), "prefill distort_recent")
+
+
+@pytest.mark.parametrize("use_dl", [False, True], ids=["host-lengths", "device-lengths"])
+def test_paged_cache_pipeline(use_dl, env, oracle):
+    """PagedPQCache end to end (paged_pq_utils.py:216-386): bulk prefill encode straight into pages (prompt length not
+    a multiple of the page), 150 decode steps with fused append, two ring flushes that straddle pages; batch 2, GQA,
+    two layers; every 25th step against the oracle fed with the oracle's own codes."""
+    torch, ops = env
+    from million_amd.pq_cache import PagedPQCache
+    bs, nh, nhk, d, M, C, ps, L_ = 2, 8, 2, 128, 64, 256, 64, 2
+    n_prompt, n_dec = 3000, 150
+    rs = np.random.RandomState(12)
+    ck, cv = rs.standard_normal((M, C, 2)).astype(np.float16), rs.standard_normal((M, C, 2)).astype(np.float16)
+    K = rs.standard_normal((L_, bs, nhk, n_prompt + n_dec, d)).astype(np.float16)
+    V = rs.standard_normal((L_, bs, nhk, n_prompt + n_dec, d)).astype(np.float16)
+    Q = rs.standard_normal((n_dec, L_, bs, nh, 1, d)).astype(np.float16)
+    cache = PagedPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=L_, d=d, page_size=ps,
+                         extended_residual_size=128, max_tokens=n_prompt + n_dec + 256)
+    cache.set_cent(torch.from_numpy(ck).cuda(), torch.from_numpy(cv).cuda())
+    Kd, Vd = torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda()
+    for l in range(L_):
+        qp = torch.from_numpy(rs.standard_normal((bs, nh, n_prompt, d)).astype(np.float16)).cuda()
+        cache.prefill(qp, Kd[l, :, :, :n_prompt].contiguous(), Vd[l, :, :, :n_prompt].contiguous(), l)
+    pol = oracle.PagedPolicy(page_size=ps, residual=128, prefill=n_prompt)
+    for i in range(n_dec):
+        t = n_prompt + i
+        outs = [cache.decoding_with_pages(torch.from_numpy(Q[i, l]).cuda(), Kd[l, :, :, t:t + 1].contiguous(),
+                                          Vd[l, :, :, t:t + 1].contiguous(), l, use_dev_lengths=use_dl) for l in range(L_)]
+        T, r = pol.step()
+        assert (cache._T[0], cache.residualed_tokens[0]) == (T, r)
+        if i % 25 == 0 or i == n_dec - 1:
+            for l in range(L_):
+                kc, vc = oracle.pq_encode(K[l, :, :, :T], ck), oracle.pq_encode(V[l, :, :, :T], cv)
+                kres, vres = np.zeros((bs, nhk, 128, d), np.float16), np.zeros((bs, nhk, 128, d), np.float16)
+                kres[:, :, :r], vres[:, :, :r] = K[l, :, :, T:T + r], V[l, :, :, T:T + r]
+                _check(outs[l].float().cpu().numpy(), oracle.decode_attn(Q[i, l], kc, vc, ck, cv, kres, vres, r),
+                       f"step {i} layer {l}")
+    if use_dl:
+        assert cache.lengths[0].cpu().numpy()[:, :2].tolist() == [[cache._T[0], cache.residualed_tokens[0]]] * bs
