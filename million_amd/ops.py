@@ -62,10 +62,12 @@ def prepare_cents(cents: torch.Tensor, cache: bool = True) -> torch.Tensor:
 def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, layout: int = L.MILLION_CODES_ROWMAJOR,
                    token_start: int = 0, n: Optional[int] = None, page_ids: Optional[torch.Tensor] = None,
                    page_size: int = 0, x_row_start: int = 0, x_row_mod: int = 0,
-                   dev_lengths: Optional[torch.Tensor] = None, use_prepared: bool = True) -> None:
+                   dev_lengths: Optional[torch.Tensor] = None, use_prepared: bool = True,
+                   prepared: Optional[torch.Tensor] = None) -> None:
     """Encode rows of X (bs, nh_k, n_rows, d) fp16 and write the codes into `dst` in their final layout.
     use_prepared: hand the kernel the (cached) prepared codebook, whose fp32 image makes the distance loop ~1.6x
-    faster; the codes are bit-identical either way."""
+    faster; the codes are bit-identical either way.  prepared: that blob, when the caller already holds it (the caches
+    do: nothing is allocated or launched on their behalf inside a captured step)."""
     _need_cuda(X, cents, dst, page_ids)
     if X.dtype != torch.float16 or cents.dtype != torch.float16 or dst.dtype != torch.uint8:
         raise RuntimeError("pq_encode: X and cents must be fp16, dst uint8")
@@ -94,7 +96,9 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
             raise RuntimeError("pq_encode: page pool must be contiguous")
         desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
     desc.dev_lengths = _ptr(dev_lengths)
-    desc.cents_prepared = prepare_cents(cents).data_ptr() if use_prepared else None
+    if prepared is None and use_prepared:
+        prepared = prepare_cents(cents)            # cached per codebook tensor; callers that own one pass it in
+    desc.cents_prepared = _ptr(prepared)
     lib = L.load()
     L.check(lib.million_pq_encode(ctypes.byref(desc), X.data_ptr(), cents.data_ptr(), dst.data_ptr(),
                                   _ptr(page_ids), _stream()), "million_pq_encode")

@@ -226,8 +226,8 @@ class DynamicPQCache(_CacheBase):
         T = self._T[layer_idx]
         if T + n > self.max_tokens:
             raise RuntimeError(f"DynamicPQCache: {T + n} tokens exceed max_tokens={self.max_tokens}")
-        ops.pq_encode_into(X[0], self.key_cent, self._k_store[layer_idx], token_start=T, n=n)
-        ops.pq_encode_into(X[1], self.value_cent, self._v_store[layer_idx], token_start=T, n=n)
+        ops.pq_encode_into(X[0], self.key_cent, self._k_store[layer_idx], token_start=T, n=n, prepared=self._kprep)
+        ops.pq_encode_into(X[1], self.value_cent, self._v_store[layer_idx], token_start=T, n=n, prepared=self._vprep)
         self._T[layer_idx] = T + n
 
     def prefill(self, query_states, key_states, value_states, layer_idx, distort_recent=False):
@@ -367,8 +367,8 @@ class PagedPQCache(_CacheBase):
             kw.update(x_row_start=self._rstart[layer_idx], x_row_mod=self.extended_residual_size)
         if use_dev_lengths:
             kw.update(dev_lengths=self.lengths[layer_idx])
-        ops.pq_encode_into(K, self.key_cent, self.key_page_pool, layout=L.MILLION_CODES_KPAGES, **kw)
-        ops.pq_encode_into(V, self.value_cent, self.value_page_pool, layout=L.MILLION_CODES_VPAGES, **kw)
+        ops.pq_encode_into(K, self.key_cent, self.key_page_pool, layout=L.MILLION_CODES_KPAGES, prepared=self._kprep, **kw)
+        ops.pq_encode_into(V, self.value_cent, self.value_page_pool, layout=L.MILLION_CODES_VPAGES, prepared=self._vprep, **kw)
 
     def prefill(self, query_states, key_states, value_states, layer_idx, distort_recent=False):
         """Bulk encode of the prompt straight into pages (reference paged_pq_utils.py:216-320: encode,
