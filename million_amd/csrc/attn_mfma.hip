@@ -40,7 +40,6 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int kNW = 8;                       // waves per workgroup
-static_assert(true, "");
 constexpr int kRing = 4;                     // 32-token units in flight per wave (16 VGPRs each)
 constexpr int kTabBytes = 64 * 1024;         // one codebook image (M*C*dm*2)
 constexpr int kVBase = kTabBytes;            // V col image behind the K row image
@@ -575,8 +574,10 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         }
     }
     __syncthreads();
-    float *part = (float *)(smem + kPartOff);
-    int *flag = (int *)(part + G * 128 + 2 * G + 4);
+    // each thread combines the 8 wave partials of its output element(s) and publishes straight from registers
+    // (sc1 write-through stores into this split's workspace slot): no LDS staging, no extra barrier
+    int *flag = (int *)(smem + kPartOff);
+    float *dst = slot_ptr(p, b, hk, split);
     for (int e = tid; e < G * 128; e += kNW * 64) {
         const int g = e >> 7;
         float mw[kNW], vw[kNW], lw[kNW];
@@ -597,15 +598,14 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
             acc = fmaf(f, vw[w], acc);
             lsum = fmaf(f, lw[w], lsum);
         }
-        part[e] = acc;
+        st_agent(dst + e, acc);
         if ((e & 127) == 0) {
-            part[G * 128 + g] = Mx;
-            part[G * 128 + G + g] = lsum;
+            st_agent(dst + G * 128 + g, Mx);
+            st_agent(dst + G * 128 + G + g, lsum);
         }
     }
-    __syncthreads();
     STAMP(5);
-    publish_and_merge(p, b, hk, split, part, scr_l, flag);
+    ticket_and_merge(p, b, hk, scr_l, flag);      // its first barrier also fences the scratch reads above from the reuse below
     MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
     if (dbg_on && lane < kStampSlots) {              // copy this wave's LDS stamps out (slots it wrote)
         const unsigned long long v =
@@ -965,7 +965,6 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
     m_run = m_new;
 }
 
-template <bool HAS_CODES>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1262,7 +1261,7 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_mfma_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_mfma_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         attr_set = true;
     }
     // the pipelined kernel (M = 64) runs every wave through 4 units (+ a fifth where it exists): splits of 25..40 units
@@ -1270,7 +1269,7 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         if (p.T > 0) hipLaunchKernelGGL((attn_mfma_kernel<true, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_mfma_kernel<false, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     } else if (g_mfma_policy != 1 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
-        hipLaunchKernelGGL(attn_mfma_pipe_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+        hipLaunchKernelGGL(attn_mfma_pipe_kernel, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else if (p.T > 0)
         hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else

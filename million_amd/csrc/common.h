@@ -110,15 +110,27 @@ __device__ __forceinline__ float ld_agent(const float *p) {
 // part_lds: this workgroup's partial in LDS: O[G][d] (unnormalised, relative to m), then m[G] (log2
 // domain), then l[G].  scratch: >= (2*nslots*G + 2*G) floats of LDS nobody else uses any more.
 // flag_lds: one int of LDS scratch.  All threads of the workgroup call this.
+// ticket_and_merge: the caller has ISSUED the sc1 stores of its partial into slot_ptr(p, b, hk, slot) (every
+// storing thread of the workgroup, straight from registers if it likes); this drains them, takes the ticket and,
+// in the last-arriving workgroup, merges.  publish_and_merge: the same with the partial staged in LDS.
+__device__ __forceinline__ float *slot_ptr(const AttnParams &p, int b, int hk, int slot) {
+    return p.ws_part + ((long long)(b * p.nh_k + hk) * p.nslots + slot) * p.slot_floats;
+}
+__device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int hk, float *scratch, int *flag_lds);
+
 __device__ __forceinline__ void publish_and_merge(const AttnParams &p, int b, int hk, int slot,
                                                   const float *part_lds, float *scratch, int *flag_lds) {
+    const int nvals = p.G * p.d + 2 * p.G;
+    float *dst = slot_ptr(p, b, hk, slot);
+    for (int i = threadIdx.x; i < nvals; i += blockDim.x) st_agent(dst + i, part_lds[i]);
+    ticket_and_merge(p, b, hk, scratch, flag_lds);
+}
+
+__device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int hk, float *scratch, int *flag_lds) {
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int bh = b * p.nh_k + hk;
     const int G = p.G, d = p.d;
-    const int nvals = G * d + 2 * G;
-    float *dst = p.ws_part + ((long long)bh * p.nslots + slot) * p.slot_floats;
-    for (int i = tid; i < nvals; i += nthr) st_agent(dst + i, part_lds[i]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
