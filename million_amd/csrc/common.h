@@ -110,6 +110,65 @@ __device__ __forceinline__ float ld_agent(const float *p) {
 // part_lds: this workgroup's partial in LDS: O[G][d] (unnormalised, relative to m), then m[G] (log2
 // domain), then l[G].  scratch: >= (2*nslots*G + 2*G) floats of LDS nobody else uses any more.
 // flag_lds: one int of LDS scratch.  All threads of the workgroup call this.
+// Last-arriver combine with 16-byte sc1 loads: the scalar form below issues one 4-byte agent-scope load per
+// (element, slot) - 256 wave-level requests of 256 B for 32 slots x 512 elements, ~1.9 us of load-path time on
+// the critical path of the whole launch; here a thread owns 4 consecutive output elements of nthr / (G*d/4)
+// interleaved slot subsets: 64 requests of 1 KiB, then one LDS reduction over the subsets.
+// Returns false (nothing done) for shapes it does not cover.
+typedef unsigned mv4u __attribute__((ext_vector_type(4)));
+typedef float mv4f __attribute__((ext_vector_type(4)));
+template <int G_>
+__device__ __forceinline__ void merge_vec4(const AttnParams &p, int b, int hk, const float *src, int ns, float *scratch) {
+    constexpr int kThreads = 512, kD = 128;
+    constexpr int nq = G_ * kD / 4;            // float4 groups of the output
+    constexpr int nsg = kThreads / nq;         // slot subsets = threads per group
+    constexpr int kPer = (32 + nsg - 1) / nsg; // loads per thread (ns <= 32)
+    const int tid = threadIdx.x;
+    const int q = tid % nq, sg = tid / nq;
+    const int g = (4 * q) / kD;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+    mv4u v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int slot = sg + k * nsg;
+        const int sl = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load
+        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sl * p.slot_floats + 4 * q) * 4, 0, 16 /* sc1 */);
+    }
+    // softmax weights of the slots (lane = slot), as in the scalar form
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int gg = wv; gg < G_; gg += kThreads / 64) {
+            const bool on = lane < ns;
+            const float m0 = on ? ld_agent(src + (long long)lane * p.slot_floats + G_ * kD + gg) : -INFINITY;
+            const float l0 = on ? ld_agent(src + (long long)lane * p.slot_floats + G_ * kD + G_ + gg) : 0.f;
+            const float mx = wave_max(m0);
+            const float ms_ = mx > -INFINITY ? mx : 0.f;
+            const float w0 = exp2f(m0 - ms_);
+            const float den = wave_sum(w0 * l0);
+            const float inv = den > 0.f ? 1.0f / den : 0.f;
+            if (on) scratch[lane * G_ + gg] = w0 * inv;
+        }
+    }
+    __syncthreads();
+    mv4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int slot = sg + k * nsg;
+        const float w = slot < ns ? scratch[slot * G_ + g] : 0.f;
+        acc += w * __builtin_bit_cast(mv4f, v[k]);
+    }
+    mv4f *red = (mv4f *)(scratch + 512);       // behind the (<= 32 * 8) weights
+    red[sg * nq + q] = acc;
+    __syncthreads();
+    if (sg == 0) {
+#pragma unroll
+        for (int j = 1; j < nsg; ++j) acc += red[j * nq + q];
+        typedef f16 h4 __attribute__((ext_vector_type(4)));
+        const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+        *(h4 *)(p.out + ((long long)b * p.nh + hk * G_) * kD + 4 * q) = o;
+    }
+}
+
 // ticket_and_merge: the caller has ISSUED the sc1 stores of its partial into slot_ptr(p, b, hk, slot) (every
 // storing thread of the workgroup, straight from registers if it likes); this drains them, takes the ticket and,
 // in the last-arriving workgroup, merges.  publish_and_merge: the same with the partial staged in LDS.
@@ -149,6 +208,15 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     constexpr int kMergeBatch = 32;
     const int ns = p.nslots;
     const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
+    if (nthr == 512 && d == 128 && ns <= 32 && (G == 1 || G == 2 || G == 4 || G == 8)) {      // workgroup-uniform
+        MILLION_STAMP(p, 11);
+        if (G == 4) merge_vec4<4>(p, b, hk, src, ns, scratch);
+        else if (G == 8) merge_vec4<8>(p, b, hk, src, ns, scratch);
+        else if (G == 2) merge_vec4<2>(p, b, hk, src, ns, scratch);
+        else merge_vec4<1>(p, b, hk, src, ns, scratch);
+        goto merged;
+    }
+    {
     const bool fast = (G * d <= nthr) && (ns <= kMergeBatch);      // workgroup-uniform: straight-line path
     float v[kMergeBatch];
     if (fast) {
@@ -204,6 +272,8 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
             p.out[((long long)b * p.nh + hk * G + g) * d + (e - g * d)] = (f16)acc;
         }
     }
+    }
+merged:
     if (tid == 0) {
         __hip_atomic_store(p.ws_cnt + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // fused append with device-resident lengths: every workgroup of batch b has read its lengths once
