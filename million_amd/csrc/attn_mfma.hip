@@ -574,34 +574,39 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         }
     }
     __syncthreads();
-    // each thread combines the 8 wave partials of its output element(s) and publishes straight from registers
-    // (sc1 write-through stores into this split's workspace slot): no LDS staging, no extra barrier
+    // a thread combines the 8 wave partials of 4 consecutive output elements (16-byte LDS reads) and publishes them
+    // straight from registers with one 16-byte sc1 (write-through) store into this split's workspace slot
     int *flag = (int *)(smem + kPartOff);
     float *dst = slot_ptr(p, b, hk, split);
-    for (int e = tid; e < G * 128; e += kNW * 64) {
-        const int g = e >> 7;
-        float mw[kNW], vw[kNW], lw[kNW];
+    {
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, 0x7fffffff, 0x00020000);
+        for (int q = tid; q < G * 32; q += kNW * 64) {
+            const int g = q >> 5;
+            float mw[kNW], lw[kNW];
+            v4f32 vw[kNW];
 #pragma unroll
-        for (int w = 0; w < kNW; ++w) {
-            mw[w] = scr_l[w * wstride + G * 128 + g];
-            vw[w] = scr_l[w * wstride + e];
-            lw[w] = scr_l[w * wstride + G * 128 + kMaxG + g];
-        }
-        float Mx = mw[0];
+            for (int w = 0; w < kNW; ++w) {
+                mw[w] = scr_l[w * wstride + G * 128 + g];
+                vw[w] = *(const v4f32 *)(scr_l + w * wstride + 4 * q);
+                lw[w] = scr_l[w * wstride + G * 128 + kMaxG + g];
+            }
+            float Mx = mw[0];
 #pragma unroll
-        for (int w = 1; w < kNW; ++w) Mx = fmaxf(Mx, mw[w]);
-        const float Ms = Mx > -INFINITY ? Mx : 0.f;
-        float acc = 0.f, lsum = 0.f;
+            for (int w = 1; w < kNW; ++w) Mx = fmaxf(Mx, mw[w]);
+            const float Ms = Mx > -INFINITY ? Mx : 0.f;
+            v4f32 acc = {0.f, 0.f, 0.f, 0.f};
+            float lsum = 0.f;
 #pragma unroll
-        for (int w = 0; w < kNW; ++w) {
-            const float f = fast_exp2(mw[w] - Ms);      // -inf -> 0
-            acc = fmaf(f, vw[w], acc);
-            lsum = fmaf(f, lw[w], lsum);
-        }
-        st_agent(dst + e, acc);
-        if ((e & 127) == 0) {
-            st_agent(dst + G * 128 + g, Mx);
-            st_agent(dst + G * 128 + G + g, lsum);
+            for (int w = 0; w < kNW; ++w) {
+                const float f = fast_exp2(mw[w] - Ms);      // -inf -> 0
+                acc += f * vw[w];
+                lsum = fmaf(f, lw[w], lsum);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 16 /* sc1 */);
+            if ((q & 31) == 0) {
+                st_agent(dst + G * 128 + g, Mx);
+                st_agent(dst + G * 128 + G + g, lsum);
+            }
         }
     }
     STAMP(5);
