@@ -565,3 +565,22 @@ def test_paged_cache_pipeline(use_dl, env, oracle):
                        f"step {i} layer {l}")
     if use_dl:
         assert cache.lengths[0].cpu().numpy()[:, :2].tolist() == [[cache._T[0], cache.residualed_tokens[0]]] * bs
+
+
+@pytest.mark.parametrize("G", [3, 5, 6, 7])
+def test_attn_odd_group_sizes(G, env, oracle):
+    """GQA group sizes that are not powers of two (scalar last-arriver combine, partially filled MFMA columns)."""
+    torch, ops = env
+    nhk = 2
+    c = synth.attn_case(900 + G, 1, G * nhk, nhk, 128, 64, 256, 2100, 77)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, f"G={G} paged")
+    _check(_run_rowmajor(torch, ops, c, 64, 256), gold, f"G={G} rowmajor")
+
+
+def test_attn_nothing_to_attend(env):
+    """T = 0 and r = 0: the reference divides 0 by 0 (NaN); here the documented result is zeros."""
+    torch, ops = env
+    c = synth.attn_case(5, 2, 8, 2, 128, 64, 256, 0, 0)
+    out = _run_rowmajor(torch, ops, c, 64, 256)
+    assert np.array_equal(out, np.zeros_like(out))
