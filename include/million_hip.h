@@ -114,6 +114,7 @@ int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n
  *
  * out[b,h,:] = softmax_j( q[b,h,:] . Kfull[b,hk,j,:] / sqrt(d) ) Vfull[b,hk,j,:],  hk = h / (nh/nh_k),
  * Kfull = [ dequant(k codes, T tokens) ; k_resid valid rows (r rows) ], likewise V.
+ * T = 0 and r = 0 (nothing to attend to): out = 0 (the reference divides 0 by 0).
  */
 enum {
     MILLION_KV_ROWMAJOR = 0,      /* codes (bs, nh_k, T_cap, M) u8: reference layout (Interface.template.cu:29-30) */
