@@ -675,8 +675,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     const int r_old = dl[1], rstart = dl[2];
     const int r = r_old + (p.k_new ? 1 : 0);       // fused append: the new token is window row r_old
     if (T < 1) T = 0;
-    const int t_begin = min(split * p.split_len, T);
-    const int t_end = min(t_begin + p.split_len, T);
+    // The T tokens that are actually there (device-resident lengths: the host sized the grid for its BOUND on T) are
+    // dealt to the nsplit splits in whole 32-token units, as evenly as units allow: the first (units % nsplit) splits
+    // carry one unit more.  (Uniform split lengths rounded up to a page left the last splits short or empty and made
+    // most waves of the others run a fifth unit as soon as T passed 32 x 1024.)
+    const int units_total = (T + 31) >> 5;
+    const int units_q = units_total / p.nsplit, units_r = units_total - units_q * p.nsplit;
+    const int u_begin = split * units_q + (split < units_r ? split : units_r);
+    const int t_begin = u_begin << 5;
+    const int t_end = min((u_begin + units_q + (split < units_r ? 1 : 0)) << 5, T);
     const int n_units = (t_end - t_begin + 31) >> 5;
     const int n_mine = n_units > wave ? (n_units - wave + kNW - 1) / kNW : 0;   // units of this wave
     const int n_pass = (n_mine + kRing - 1) / kRing;
@@ -1014,8 +1021,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
     const int r_old = dl[1], rstart = dl[2];
     const int r = r_old + (p.k_new ? 1 : 0);
     if (T < 1) T = 0;
-    const int t_begin = min(split * p.split_len, T);
-    const int t_end = min(t_begin + p.split_len, T);
+    // The T tokens that are actually there (device-resident lengths: the host sized the grid for its BOUND on T) are
+    // dealt to the nsplit splits in whole 32-token units, as evenly as units allow: the first (units % nsplit) splits
+    // carry one unit more.  (Uniform split lengths rounded up to a page left the last splits short or empty and made
+    // most waves of the others run a fifth unit as soon as T passed 32 x 1024.)
+    const int units_total = (T + 31) >> 5;
+    const int units_q = units_total / p.nsplit, units_r = units_total - units_q * p.nsplit;
+    const int u_begin = split * units_q + (split < units_r ? split : units_r);
+    const int t_begin = u_begin << 5;
+    const int t_end = min((u_begin + units_q + (split < units_r ? 1 : 0)) << 5, T);
     const int n_units = (t_end - t_begin + 31) >> 5;
     const int n_mine = n_units > wave ? (n_units - wave + kNW - 1) / kNW : 0;
     const int T_ld = T > 0 ? T : 1;
@@ -1250,12 +1264,13 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     const int by_len = p.T > 0 ? (p.T + 511) / 512 : 1;
     if (ns > by_len) ns = by_len;
     if (ns < 1) ns = 1;
-    int len = p.T > 0 ? (p.T + ns - 1) / ns : 64;
-    len = (len + 63) / 64 * 64;
-    ns = p.T > 0 ? (p.T + len - 1) / len : 1;
+    // the kernels deal whole 32-token units to the splits (first units % ns splits carry one more): len = the longest
+    const int units = p.T > 0 ? (p.T + 31) / 32 : 1;
+    if (ns > units) ns = units;
+    int len = 32 * ((units + ns - 1) / ns);
     if (g_mfma_policy == 2 && len > 40 * 32 && 2 * ns <= kMaxSplits) {
-        const int len2 = ((p.T + 2 * ns - 1) / (2 * ns) + 63) / 64 * 64;
-        if (len2 > 24 * 32 && len2 <= 40 * 32) { len = len2; ns = (p.T + len - 1) / len; }
+        const int len2 = 32 * ((units + 2 * ns - 1) / (2 * ns));
+        if (len2 > 24 * 32 && len2 <= 40 * 32) { len = len2; ns = 2 * ns; }
     }
     p.nsplit = ns;
     p.nslots = ns;
