@@ -1015,6 +1015,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
     //      1-KiB wave request (measured: 12 more requests per wave in front of the barrier moved it by 1.7 us),
     //      so only what the first scores need is requested before the K-codebook barrier - the first unit's
     //      code bytes (HBM latency) ahead of the codebook (L2) - and the rest rides between compute stages. ----
+    // the first half of the K codebook goes out before the scalar round trips (lengths, page ids) that the code
+    // requests need: their latency hides behind it
+    v4u tabk[8], tabv[8];
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
+    {
+        const v4u *ks = (const v4u *)p.k_tab;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+    }
     if (p.dev_lengths)
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
     int T = dl[0] < p.T ? dl[0] : p.T;
@@ -1047,12 +1056,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
     }
     load_unit_k(p, b, hk, pid4[0], UNIT_T(0), T_ld, lane, ring[0]);
     load_unit_v(p, pid4[0], UNIT_T(0), lane, ring[0]);
-    v4u tabk[8], tabv[8];
-    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
     {
         const v4u *ks = (const v4u *)p.k_tab;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+        for (int i = 4; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
     }
     load_unit_k(p, b, hk, pid4[1], UNIT_T(1), T_ld, lane, ring[1]);
     load_unit_v(p, pid4[1], UNIT_T(1), lane, ring[1]);
