@@ -584,3 +584,40 @@ def test_attn_nothing_to_attend(env):
     c = synth.attn_case(5, 2, 8, 2, 128, 64, 256, 0, 0)
     out = _run_rowmajor(torch, ops, c, 64, 256)
     assert np.array_equal(out, np.zeros_like(out))
+
+
+def test_paged_cache_on_demand_pages_and_stats(env, oracle):
+    """PagedPQCache(preallocate=False): pages are taken from the PageManager as tokens arrive (prefill and each
+    flush), the result is the same as with a preallocated table, and get_cache_stats reports the reference's keys
+    (paged_pq_utils.py:898-939)."""
+    torch, ops = env
+    from million_amd.pq_cache import PagedPQCache
+    bs, nh, nhk, d, M, ps = 1, 8, 2, 128, 64, 64
+    rs = np.random.RandomState(21)
+    ck, cv = rs.standard_normal((M, 256, 2)).astype(np.float16), rs.standard_normal((M, 256, 2)).astype(np.float16)
+    n_prompt, n_dec = 130, 140
+    K = torch.from_numpy(rs.standard_normal((bs, nhk, n_prompt + n_dec, d)).astype(np.float16)).cuda()
+    V = torch.from_numpy(rs.standard_normal((bs, nhk, n_prompt + n_dec, d)).astype(np.float16)).cuda()
+    Q = torch.from_numpy(rs.standard_normal((n_dec, bs, nh, 1, d)).astype(np.float16)).cuda()
+    outs = {}
+    for pre in (True, False):
+        cache = PagedPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, page_size=ps,
+                             extended_residual_size=128, max_tokens=1024, preallocate=pre)
+        cache.set_cent(torch.from_numpy(ck).cuda(), torch.from_numpy(cv).cuda())
+        if not pre:
+            assert cache.page_manager.get_stats()["allocated_pages"] == 0
+        cache.prefill(Q[0].expand(-1, -1, 1, -1).repeat(1, 1, n_prompt, 1), K[:, :, :n_prompt].contiguous(),
+                      V[:, :, :n_prompt].contiguous(), 0)
+        o = []
+        for i in range(n_dec):
+            t = n_prompt + i
+            o.append(cache.decoding_with_pages(Q[i], K[:, :, t:t + 1].contiguous(), V[:, :, t:t + 1].contiguous(), 0))
+        outs[pre] = torch.stack(o).float().cpu().numpy()
+        st = cache.get_cache_stats()
+        assert st["layer_stats"][0]["seen_tokens"] == n_prompt + n_dec
+        assert st["layer_stats"][0]["key_cache_tokens"] == cache._T[0] == n_prompt + 64      # one flush (step 129)
+        assert st["layer_stats"][0]["residual_tokens"] == cache.residualed_tokens[0]
+        assert set(st["memory_breakdown"]) >= {"cache_memory_mb", "residual_memory_mb", "total_memory_mb"}
+        if not pre:      # 194 tokens -> 4 pages per (b, hk), taken only when needed
+            assert st["page_manager"]["allocated_pages"] == 4 * bs * nhk
+    np.testing.assert_array_equal(outs[True], outs[False])
