@@ -767,6 +767,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #define GROUP(PASS, MASKV, FIRST, REFILL)                                                                          \
     {                                                                                                              \
         float sc[kRing][8], scr[4];                                                                                \
+        /* page ids of the units this group refills the ring with: ONE scalar round trip per group, up front (a   */  \
+        /* per-unit s_load + lgkmcnt(0) inside the value pass drained the LDS gather queue four times per group)  */  \
+        PidPair pidr[kRing];                                                                                       \
+        if (HAS_CODES && (REFILL)) {                                                                               \
+            int pgr[kRing];                                                                                        \
+            _Pragma("unroll") for (int k = 0; k < kRing; ++k) pgr[k] = UNIT_T(((PASS) + 1) * kRing + k) >> p.ps_shift; \
+            load_pids4(p, bh, pgr, pidr);                                                                          \
+        }                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < kRing; ++k) {                                                        \
             const int j = (PASS) * kRing + k;                                                                      \
             if (HAS_CODES && j < n_mine)                                                                           \
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         _Pragma("unroll") for (int k = 0; k < kRing; ++k) {                                                        \
             const int j = (PASS) * kRing + k;                                                                      \
             if (HAS_CODES && j < n_mine) value_unit(ring[k].v, sc[k], vconst0, vconst1, O);                        \
-            if (HAS_CODES && (REFILL)) load_unit(p, b, hk, bh, UNIT_T(j + kRing), T_ld, lane, ring[k]);            \
+            if (HAS_CODES && (REFILL)) load_unit_pid(p, b, hk, pidr[k], UNIT_T(j + kRing), T_ld, lane, ring[k]);   \
         }                                                                                                          \
     }
 
