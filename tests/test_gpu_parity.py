@@ -621,3 +621,19 @@ def test_paged_cache_on_demand_pages_and_stats(env, oracle):
         if not pre:      # 194 tokens -> 4 pages per (b, hk), taken only when needed
             assert st["page_manager"]["allocated_pages"] == 4 * bs * nhk
     np.testing.assert_array_equal(outs[True], outs[False])
+
+
+# ---- splits of >= 64 units (several ring refills per wave) --------------------------------------------------
+@pytest.mark.parametrize("T,r,nh,nhk,bs", [
+    (65536, 100, 32, 8, 1),      # 64 units per split: 8 per wave, two rounds, no phantom units
+    (66000, 128, 32, 8, 1),      # ragged: waves with 8 or 9 units, the closing chain runs masked units
+    (32768 + 64, 7, 8, 8, 2),    # batch 2 (16 splits per kv head, 65 units); G = 1
+    (131072, 64, 16, 8, 1),      # 128 units per split: four rounds; G = 2
+    (90000, 1, 64, 8, 1),        # G = 8
+])
+def test_attn_long_splits(T, r, nh, nhk, bs, env, oracle):
+    torch, ops = env
+    c = synth.attn_case(6000 + T % 983 + r, bs, nh, nhk, 128, 64, 256, T, r)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, f"paged T={T}")
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 128, k_paged=False, i64=True, shuffle=False), gold, f"mixed T={T}")
