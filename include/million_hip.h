@@ -141,7 +141,9 @@ typedef struct {
     int64_t k_stride_b, k_stride_h;   /* ROWMAJOR: bytes between batches / kv heads of k_codes */
     int64_t v_stride_b, v_stride_h;   /* ROWMAJOR: same for v_codes */
     const int32_t *dev_lengths;   /* optional device array (bs, 4) = {n_tokens, r, resid_start, 0}: when set,
-                                     lengths are read on the device (graph replay with changing lengths) */
+                                     lengths are read on the device (graph replay with changing lengths); every
+                                     batch item has its own row, so requests of different lengths can share a
+                                     launch - n_tokens above is then only the bound the grid is sized for */
 } million_attn_desc;
 
 size_t million_attn_workspace_bytes(const million_attn_desc *desc);

@@ -637,3 +637,32 @@ def test_attn_long_splits(T, r, nh, nhk, bs, env, oracle):
     gold = oracle.decode_attn(**c)
     _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, f"paged T={T}")
     _check(_run_paged(torch, ops, oracle, c, 64, 256, 128, k_paged=False, i64=True, shuffle=False), gold, f"mixed T={T}")
+
+
+@pytest.mark.parametrize("Tmax,nh,nhk", [(1000, 8, 2), (33000, 32, 8)])
+def test_ragged_batch_device_lengths(Tmax, nh, nhk, env, oracle):
+    """Requests of different lengths in one batch: with device-resident lengths every batch item carries its own
+    (T, r, start); the host descriptor only gives the bound.  (The reference assumes one length for the batch.)"""
+    torch, ops = env
+    bs, ps, cap = 3, 64, 128
+    Ts, rs_, starts = [Tmax, 37, (Tmax * 2) // 3], [5, 128, 0], [0, 100, 7]
+    c = synth.attn_case(8100 + Tmax % 97, bs, nh, nhk, 128, 64, 256, Tmax, cap)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    kr, vr = t["k_res"].clone(), t["v_res"].clone()
+    for b in range(bs):      # ring start per batch item
+        kr[b] = torch.roll(t["k_res"][b], starts[b], dims=1)
+        vr[b] = torch.roll(t["v_res"][b], starts[b], dims=1)
+    lengths = torch.tensor([[Ts[b], rs_[b], starts[b], 0] for b in range(bs)], dtype=torch.int32, device="cuda")
+    out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda(), kp, vp, kr, vr, 0,
+                             M=64, C=256, n_tokens=Tmax, k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps,
+                             dev_lengths=lengths)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    for b in range(bs):
+        cb = {k: (v[b:b + 1] if isinstance(v, np.ndarray) and v.shape[0] == bs else v) for k, v in c.items()}
+        cb["k_codes"], cb["v_codes"], cb["r"] = cb["k_codes"][:, :, :Ts[b]], cb["v_codes"][:, :, :Ts[b]], rs_[b]
+        _check(o[b:b + 1], oracle.decode_attn(**cb), f"batch item {b} (T={Ts[b]}, r={rs_[b]})")
