@@ -121,21 +121,26 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
 
 // Small calls (a flush of 64 window rows: 512 (row, subspace) pairs per kv head) cannot hide the scalar-cache
 // round trips of the kernel above behind other waves: 32 dependent s_load batches of ~0.6 us each.  This variant
-// puts the wave's centroid row into LDS with ONE vector round trip (converted to fp32 on the way) and reads it back
-// with wave-uniform (broadcast) ds_reads that pipeline; one subspace per wave for the most parallelism.
+// puts the centroid row into LDS with ONE vector round trip (converted to fp32 on the way) and reads it back with
+// wave-uniform (broadcast) ds_reads that pipeline; one subspace per workgroup, a quarter of the centroids per wave.
 template <int DM>
 __global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p) {
-    __shared__ float rows[kEncBlock / 64][256 * DM];
+    // one subspace and 64 tokens per WORKGROUP: its four waves scan a quarter of the centroids each (a 4x shorter
+    // dependent chain), wave 0 picks among the four candidates in centroid order (strict '<': lowest index on ties)
+    constexpr int kW = kEncBlock / 64;
+    __shared__ float rows[256 * DM];
+    __shared__ float cand_d[kW][64];
+    __shared__ int cand_c[kW][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int m = blockIdx.y * (kEncBlock / 64) + w;
+    const int m = blockIdx.y;
     const int bh = blockIdx.z;
     const int b = bh / p.nh_k, hk = bh % p.nh_k;
     const int t = blockIdx.x * 64 + lane;
-    if (m >= p.M) return;
+    const int cq = (p.C + kW - 1) / kW;                   // centroids per wave
+    const int c0 = w * cq, c1 = min(c0 + cq, p.C);
     const f16 *cm = p.cents + (long long)m * p.C * DM;
-    float *row = rows[w];
-    for (int e = lane; e < p.C * DM; e += 64) row[e] = (float)cm[e];     // own region, own wave: LDS order suffices
+    for (int e = c0 * DM + lane; e < c1 * DM; e += 64) rows[e] = (float)cm[e];      // own quarter, own wave: LDS order suffices
     const bool valid = t < p.n;
     const int tc = valid ? t : p.n - 1;
     int tok0 = p.tok0, xrow_start = p.xrow_start;
@@ -146,20 +151,29 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p)
 #pragma unroll
     for (int k = 0; k < DM; ++k) x[k] = (float)xp[k];
     float best = INFINITY;
-    int best_c = 0;
+    int best_c = c0;
 #pragma unroll 8
-    for (int c = 0; c < p.C; ++c) {
+    for (int c = c0; c < c1; ++c) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
-            const float e = x[k] - row[c * DM + k];
+            const float e = x[k] - rows[c * DM + k];
             const float sq = e * e;
             acc = (k == 0) ? sq : acc + sq;
         }
         best_c = acc < best ? c : best_c;
         best = fminf(best, acc);
     }
-    if (!valid) return;
+    cand_d[w][lane] = best;
+    cand_c[w][lane] = best_c;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    // an empty quarter (C < 4 quarters) leaves +inf: never smaller than a real candidate; all-inf keeps quarter 0's index
+#pragma unroll
+    for (int j = 1; j < kW; ++j) {
+        const float dj = cand_d[j][lane];
+        if (dj < best) { best = dj; best_c = cand_c[j][lane]; }
+    }
     const int tok = tok0 + t;
     if (p.layout == MILLION_CODES_ROWMAJOR) {
         p.dst[b * p.dsb + hk * p.dsh + (long long)tok * p.M + m] = (uint8_t)best_c;
@@ -176,7 +190,7 @@ static void launch_dm(const EncParams &p, dim3 grid, hipStream_t s) {
     // fewer than ~one wave per SIMD with 4 subspaces per wave: latency-bound, take the LDS variant
     const long long waves4 = (long long)grid.x * grid.y * (kEncBlock / 64) * grid.z;
     if (waves4 < 1024) {
-        dim3 g1(grid.x, (p.M + kEncBlock / 64 - 1) / (kEncBlock / 64), grid.z);
+        dim3 g1(grid.x, p.M, grid.z);
         hipLaunchKernelGGL((pq_encode_small_kernel<DM>), g1, dim3(kEncBlock), 0, s, p);
         return;
     }
