@@ -4,30 +4,40 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], "Llama-3.1-8B-hf (GQA), 32K context, PQ M=64 nbits=8, batch=1"):
-one STEP = one decode token through the hot path of all 32 layers of one request per GPU — per layer:
-residual-window append of the new K/V row, flush of the oldest 64 rows into a new K page and V page when
-the window is full (PQ encode), and the fused decode attention over the PagedPQCache (T ~ 32K quantised
-tokens + residual window), nh=32 q heads, nh_k=8 kv heads, d=128.  Synthetic data exactly as the reference's
-micro-benchmark (scripts/modeldb/bindings/test_kernel.py:59-65): q/residuals/centroids ~ N(0,1) fp16, codes
-~ U{0..255}.  Each layer has its own 33.5 MB of code pages (1.07 GB per step), so the Infinity Cache cannot
-hold the working set.  The model's projections / MLP are NOT part of this path (harness glue
-is a "next" row) — `value` is hot-path tokens/s, and is labelled so.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N
+ranks (as a CHILD process, before anything has touched the GPU) and exits with the child's code, so the one-line
+form works too.
 
-A step is replayed from a hipGraph (lengths live on the device), timed over exactly K steps between
-barrier + synchronize on both sides; N > 1 shards REQUESTS over ranks (one request per GPU, no data-path
-collective: SURVEY.md 8e), value = all ranks' tokens / max-over-ranks time.
+Workload (BASELINE.json configs[2], "Llama-3.1-8B-hf (GQA), 32K context, PQ M=64 nbits=8, batch=1"; with N > 1 the
+default becomes configs[3]: 2 requests per GPU, 16 requests over 8 GPUs): one STEP = one decode token through the hot
+path of all 32 layers of the rank's requests — per layer: residual-window append of the new K/V row, flush of the
+oldest 64 rows into a new K page and V page when the window is full (PQ encode), and the fused decode attention over
+the PagedPQCache (T ~ 32K quantised tokens + residual window), nh=32 q heads, nh_k=8 kv heads, d=128.  Synthetic data
+exactly as the reference's micro-benchmark (scripts/modeldb/bindings/test_kernel.py:59-65): q/residuals/centroids ~
+N(0,1) fp16, codes ~ U{0..255}.  Each layer has its own 33.5 MB of code pages (1.07 GB per step), so the Infinity
+Cache cannot hold the working set.  The model's projections / MLP are NOT part of this path (harness
+glue is a "next" row, timed by tools/e2e_speedtest.py) — `value` is hot-path tokens/s, and is labelled so.
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the fused decode-attention launch:
-algorithmic bytes per launch / mean launch duration from HIP events recorded on the launch stream) and
-`cpu_baseline` (the reference's CPU PyTorch math restated in oracle/, timed on this box's cores on ONE
-layer-call and scaled to a step; rank 0, N = 1 only).
+A step is replayed from a hipGraph (lengths live on the device), timed over exactly K steps between barrier +
+synchronize on both sides; the window fill at the start is chosen so that ONE flush step (encode of a page per layer)
+falls inside the timed region; N > 1 shards REQUESTS over ranks (no data-path collective: SURVEY.md 8e), value = all
+ranks' tokens / max-over-ranks time.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the fused decode-attention launch: algorithmic bytes
+per launch / mean launch duration from HIP events recorded on the launch stream), `cpu_baseline` (the reference's CPU
+PyTorch math restated in oracle/, timed on this box's cores on ONE layer-call and scaled to a step; rank 0, N = 1
+only) and `gpu_fp16_baseline` (one layer-call of the reference's fp16 full-KV recipe — torch.cat + repeat_kv + SDPA,
+scripts/modeldb/models/modeling_llama.py:403-443 — and of SDPA on a preallocated cache, same shape, HIP events);
+`vs_baseline` = that recipe's layer-call time / this path's layer-call time (kernel level; BASELINE.md holds no
+published number for the metric itself).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -39,23 +49,30 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--ctx", type=int, default=32768, help="quantised context length T at the start")
     ap.add_argument("--layers", type=int, default=32)
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="requests per rank (default: 1, or 2 when --gpus > 1 = BASELINE configs[3])")
     ap.add_argument("--M", type=int, default=64)
     ap.add_argument("--nh", type=int, default=32)
     ap.add_argument("--nh-k", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp16-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--force-generic", action="store_true", help="A/B: use the generic LUT kernel")
-    ap.add_argument("--kernel-policy", type=int, default=0, help="A/B: 2 = grouped MFMA kernel only, 3 = prefer the pipelined one")
+    ap.add_argument("--kernel-policy", type=int, default=0, help="A/B knob passed to million_set_force_generic")
     ap.add_argument("--roofline-launches", type=int, default=256)
-    return ap.parse_args()
+    ap.add_argument("--dry-cpu", action="store_true",
+                    help="rehearse the launcher / rank plumbing on CPU (gloo, no kernels): prints the same JSON line with "
+                         "a sleep as the step; for the CPU tests, never a measurement")
+    args = ap.parse_args(argv)
+    if args.batch_per_gpu <= 0:
+        args.batch_per_gpu = 2 if args.gpus > 1 else 1
+    return args
 
 
 def algorithmic_bytes(bs, nh, nh_k, T, r, d, M, C):
@@ -64,20 +81,61 @@ def algorithmic_bytes(bs, nh, nh_k, T, r, d, M, C):
     return 2 * bs * nh_k * T * M + 2 * bs * nh_k * r * d * 2 + 2 * M * C * dm * 2 + bs * nh * d * 2 * 2
 
 
+def window_fill_at_start(cap, warmup, steps):
+    """Residual-window fill r0 such that the first flush (the step that starts with r == cap) is step steps // 2 of the
+    timed region.  The window holds cap rows and flushes 64 of them: r cycles through (cap - 64, cap]."""
+    period = 64
+    r0 = cap - warmup - steps // 2
+    while r0 <= cap - period:
+        r0 += period
+    return max(1, min(cap, r0))
+
+
+def relaunch_under_torchrun(args):
+    """--gpus N > 1 outside a torchrun environment: start N ranks as a child process (this process has not touched the
+    GPU and never will) and return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def device_uuid(torch, idx):
+    try:
+        return str(torch.cuda.get_device_properties(idx).uuid)
+    except Exception:
+        return f"cuda:{idx}"
+
+
+def ranks_seen(dist, rank, ident):
+    """All-gather of (rank, device identity) over the job's backend (RCCL on the GPU box): proves how many ranks ran."""
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, (rank, ident))
+    return [list(x) for x in sorted(got)]
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_cpu:
+        return dry_cpu(args, torch, dist, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)     # RCCL; only barrier + max-reduce of the elapsed time
+    seen = ranks_seen(dist, rank, device_uuid(torch, local_rank)) if world > 1 else [[0, device_uuid(torch, local_rank)]]
 
     from million_amd import ops, sharding
     from million_amd.pq_cache import PagedPQCache
@@ -86,8 +144,8 @@ def main():
     bs, nh, nhk, d, M, C, layers = args.batch_per_gpu, args.nh, args.nh_k, 128, args.M, 256, args.layers
     ps, cap = 64, 128
     T0 = args.ctx // ps * ps
-    r0 = 100                                   # window fill at the start: the first flush falls inside the run
-    total_steps = args.warmup + args.steps + 4
+    r0 = window_fill_at_start(cap, args.warmup, args.steps)
+    total_steps = args.warmup + args.steps + 64 + 8
     g = torch.Generator(device="cpu").manual_seed(42 + rank)
     cache = PagedPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=layers, d=d, page_size=ps,
                          extended_residual_size=cap, max_tokens=T0 + total_steps + 2 * cap, device=dev)
@@ -149,6 +207,10 @@ def main():
     # exactly K steps between barrier + synchronize on both sides; MAX over ranks (million_amd/sharding.py)
     elapsed = sharding.timed_steps(counted_step, args.steps, torch.cuda.synchronize, dist if world > 1 else None)
     value, ms_per_step = sharding.aggregate_throughput(bs, args.steps, elapsed, world)
+    flushes_timed = n_flush_steps
+    # for the record: one whole flush period (64 steps = 63 plain + 1 flush), the steady-state mix
+    elapsed64 = sharding.timed_steps(counted_step, 64, torch.cuda.synchronize, dist if world > 1 else None)
+    value64, ms64 = sharding.aggregate_throughput(bs, 64, elapsed64, world)
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream ----
     # All (event, launch, event) triplets are enqueued behind a long device-side sleep so that the
@@ -157,20 +219,32 @@ def main():
     nl = max(layers, args.roofline_launches // layers * layers)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nl)]
     kprep, vprep = cache._kprep, cache._vprep
+
+    def attn_launch(l):
+        ops.pq_decode_attn(q[l], cache.key_page_pool, cache.value_page_pool, kprep, vprep,
+                           cache.key_residual_cache[l], cache.value_residual_cache[l], r_now, M=M, C=C,
+                           n_tokens=T_now, resid_start=cache._rstart[l], k_page_ids=cache.page_ids[l],
+                           v_page_ids=cache.page_ids[l], page_size=ps, out=outs[l], workspace=cache._ws)
+
     for rep in range(2):                       # first pass warms, second is measured
         torch.cuda._sleep(int(2.0e8 if rep else 1.0e7))
         for i in range(nl):
-            l = i % layers
             evs[i][0].record()
-            ops.pq_decode_attn(q[l], cache.key_page_pool, cache.value_page_pool, kprep, vprep,
-                               cache.key_residual_cache[l], cache.value_residual_cache[l], r_now, M=M, C=C,
-                               n_tokens=T_now, resid_start=cache._rstart[l], k_page_ids=cache.page_ids[l],
-                               v_page_ids=cache.page_ids[l], page_size=ps, out=outs[l], workspace=cache._ws)
+            attn_launch(i % layers)
             evs[i][1].record()
         torch.cuda.synchronize()
     durs = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)          # seconds
     mean_dur = sum(durs) / len(durs)
     med_dur = durs[len(durs) // 2]
+    # the same launches back to back between ONE pair of events: launch-to-launch period, no per-launch event cost
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(2.0e8))
+    e0.record()
+    for i in range(nl):
+        attn_launch(i % layers)
+    e1.record()
+    torch.cuda.synchronize()
+    period = e0.elapsed_time(e1) * 1e-3 / nl
     alg = algorithmic_bytes(bs, nh, nhk, T_now, r_now, d, M, C)
     achieved = alg / mean_dur / 1e9
     traffic = None
@@ -183,28 +257,116 @@ def main():
         except Exception:
             traffic = None
 
+    fp16 = None
+    if not args.no_fp16_baseline and not args.force_generic:
+        fp16 = gpu_fp16_baseline(torch, dev, bs, nh, nhk, d, T_now + r_now)
+
     if rank == 0:
+        cfg_name = "configs[2]" if (world == 1 and bs == 1) else ("configs[3]" if bs == 2 else "configs[2] shape")
         line = {
             "metric": "decode tokens/sec @32K ctx, Llama-3.1-8B PQ-KV attention hot path (32 layers), 1xMI355X per request",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 in/out, u8 codes, f32 accumulate", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Llama-3.1-8B shape (32 layers, nh=32, nh_k=8, d=128), "
+            "vs_baseline": (round(fp16["hf_recipe_us"] / (mean_dur * 1e6), 2) if fp16 else None),
+            "dtype": "f16 in/out, u8 codes, f32 accumulate", "data": "synthetic",
+            "config": {"workload": f"BASELINE {cfg_name}: Llama-3.1-8B shape (32 layers, nh={nh}, nh_k={nhk}, d=128), "
                                    f"ctx {T0}, PQ M={M} nbits=8, PagedPQCache page 64 / window 128, batch {bs}/GPU; "
                                    "step = 32 x (append + flush-when-full encode + fused decode attention)",
                        "ctx": T0, "layers": layers, "M": M, "batch_per_gpu": bs, "parallelism": f"requests x{world}",
-                       "flush_steps_in_timed_region": n_flush_steps,
+                       "ranks_seen": seen, "window_fill_at_start": r0,
+                       "flush_steps_in_timed_region": flushes_timed,
+                       "steady_state_64_steps": {"value": round(value64, 2), "ms_per_step": round(ms64, 4),
+                                                 "note": "one whole flush period (63 plain steps + 1 flush step)"},
                        "launch": "eager" if args.no_graph else "hipGraph replay",
                        "kernel": "generic-LUT" if args.force_generic else ("auto" if not args.kernel_policy else f"policy{args.kernel_policy}")},
             "roofline": {"bound": "hbm", "kernel": "fused decode attention (one launch per layer-call)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "launch_us_mean": round(mean_dur * 1e6, 2),
-                         "launch_us_median": round(med_dur * 1e6, 2), "launches_timed": nl},
+                         "launch_us_median": round(med_dur * 1e6, 2), "launches_timed": nl,
+                         "back_to_back_period_us": round(period * 1e6, 2)},
         }
+        if fp16:
+            line["vs_baseline_note"] = ("kernel level: reference fp16 full-KV recipe (torch.cat + repeat_kv + SDPA) layer-call "
+                                        "time / fused PQ decode-attention launch time; BASELINE.md has no published number")
+            line["gpu_fp16_baseline"] = fp16
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(bs, nh, nhk, d, M, C, T0, r0, layers)
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def gpu_fp16_baseline(torch, dev, bs, nh, nhk, d, T):
+    """One layer-call of the fp16 full-KV attention at the same shape, HIP-event timed: (a) the reference's baseline
+    recipe (modeling_llama.py:403-443: DynamicCache.update = torch.cat of the new row, repeat_kv, SDPA) and (b) SDPA on a
+    preallocated cache with the G query heads of a kv head as query rows (no cat, no repeat).  Four rotating layers of
+    K/V so that the 134 MB per layer do not sit in the Infinity Cache."""
+    import torch.nn.functional as F
+    G = nh // nhk
+    nrot = 4
+    Ks = [torch.randn(bs, nhk, T, d, device=dev, dtype=torch.float16) for _ in range(nrot)]
+    Vs = [torch.randn(bs, nhk, T, d, device=dev, dtype=torch.float16) for _ in range(nrot)]
+    q = torch.randn(bs, nh, 1, d, device=dev, dtype=torch.float16)
+    kn = torch.randn(bs, nhk, 1, d, device=dev, dtype=torch.float16)
+    vn = torch.randn(bs, nhk, 1, d, device=dev, dtype=torch.float16)
+
+    def repeat_kv(x):
+        b, h, t, dd = x.shape
+        return x[:, :, None, :, :].expand(b, h, G, t, dd).reshape(b, h * G, t, dd)
+
+    def hf(i):
+        k = torch.cat([Ks[i % nrot], kn], dim=2)
+        v = torch.cat([Vs[i % nrot], vn], dim=2)
+        return F.scaled_dot_product_attention(q, repeat_kv(k), repeat_kv(v))
+
+    def static(i):
+        qq = q.view(bs, nhk, G, d)
+        return F.scaled_dot_product_attention(qq, Ks[i % nrot], Vs[i % nrot]).view(bs, nh, 1, d)
+
+    res = {}
+    for name, fn, n in (("hf_recipe_us", hf, 24), ("preallocated_sdpa_us", static, 48)):
+        for _ in range(4):
+            fn(0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = round(e0.elapsed_time(e1) * 1e3 / n, 2)
+    res["shape"] = f"bs={bs} nh={nh} nh_k={nhk} d={d} T={T} fp16 K/V ({2 * bs * nhk * T * d * 2 / 1e6:.1f} MB per layer)"
+    res["fp16_kv_bytes_per_layer_call"] = 2 * bs * nhk * T * d * 2
+    return res
+
+
+def dry_cpu(args, torch, dist, world, rank):
+    """Launcher rehearsal on CPU (tests/test_host_logic.py): same rank plumbing, barrier, max-over-ranks timing and JSON
+    line, with a sleep as the step and gloo as the backend.  Not a measurement; nothing under oracle/ or the HIP library
+    is involved."""
+    from million_amd import sharding
+    if world > 1:
+        dist.init_process_group("gloo")
+    seen = ranks_seen(dist, rank, f"cpu-rank{rank}") if world > 1 else [[0, "cpu-rank0"]]
+    bs = args.batch_per_gpu
+
+    def step():
+        time.sleep(0.002 * (1 + rank))
+    elapsed = sharding.timed_steps(step, args.steps, lambda: None, dist if world > 1 else None)
+    value, ms = sharding.aggregate_throughput(bs, args.steps, elapsed, world)
+    n = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (cpu, gloo): launcher rehearsal, not a measurement", "value": round(value, 2),
+                          "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "none",
+                          "config": {"workload": "dry-cpu", "batch_per_gpu": bs, "parallelism": f"requests x{n}",
+                                     "ranks_seen": seen,
+                                     "window_fill_at_start": window_fill_at_start(128, args.warmup, args.steps)}}),
+              flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -259,7 +259,10 @@ class DynamicPQCache(_CacheBase):
             return key_states, value_states
         return torch.cat([past_k, key_states.to(past_k.dtype)], dim=2), torch.cat([past_v, value_states.to(past_v.dtype)], dim=2)
 
-    def decoding(self, query_states, key_states, value_states, layer_idx):
+    def decoding(self, query_states, key_states, value_states, layer_idx, fused=True):
+        """One decode step of one layer (pq_utils.py:281-328).  fused=True (default): append + attention in ONE launch.
+        fused=False: the reference's own call sequence - copy the new row into the window (:304-312), then the kernel
+        `registery.get_kernel(l=seen_tokens)` resolves by name from `bindings` (:315-325)."""
         Lt = self.max_residual_length
         if self.residualed_tokens[layer_idx] == Lt:                        # pq_utils.py:288-302
             self._append_codes((self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx]), layer_idx, Lt)
@@ -267,6 +270,14 @@ class DynamicPQCache(_CacheBase):
         r = self.residualed_tokens[layer_idx]
         self.residualed_tokens[layer_idx] = r + 1
         self.seen_tokens[layer_idx] += 1
+        if not fused:
+            ops.residual_append(key_states, value_states, self.key_residual_cache[layer_idx],
+                                self.value_residual_cache[layer_idx], r)
+            kernel = self.registery.get_kernel(l=self.seen_tokens[layer_idx])
+            T = self._T[layer_idx]
+            return kernel(query_states, self._k_store[layer_idx][:, :, :T], self._v_store[layer_idx][:, :, :T],
+                          self.key_cent, self.value_cent, self.key_residual_cache[layer_idx],
+                          self.value_residual_cache[layer_idx], r + 1)
         if self._ws is None:      # sized once for max_tokens (partials + transposed-V scratch of the row-major path)
             desc = ops.make_attn_desc(query_states, self.key_residual_cache[layer_idx], nh_k=self.num_key_value_heads,
                                       M=self.M, C=self.C, n_tokens=self.max_tokens, r=0,

@@ -57,6 +57,11 @@ def lib() -> ctypes.CDLL:
         L.pq_encode_direct_gap.restype = None
         L.pq_decode.argtypes = [c_u8, c_fp, c_fp, i64, i32, i32, i32]
         L.pq_decode.restype = None
+        c_u16 = ctypes.POINTER(ctypes.c_uint16)
+        L.pq_encode_direct_u16.argtypes = [c_fp, c_fp, c_u16, i64, i32, i32, i32]
+        L.pq_encode_direct_u16.restype = None
+        L.pq_decode_u16.argtypes = [c_u16, c_fp, c_fp, i64, i32, i32, i32]
+        L.pq_decode_u16.restype = None
         L.decode_attn_f64.argtypes = [c_fp, c_u8, c_u8, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp,
                                       i32, i32, i32, i64, i32, i32, i32, i32, i32]
         L.decode_attn_f64.restype = None
@@ -109,7 +114,12 @@ def pq_encode(X, cents) -> np.ndarray:
     cents = _f32(cents)
     bs, nhk, n, d = X.shape
     M, C, dm = cents.shape
-    assert M * dm == d and C <= 256
+    assert M * dm == d and C <= 65536
+    if C > 256:      # nbits 9..16 -> uint16 codes (nbits2dtype, pq_utils.py:542-552)
+        codes = np.empty((bs, nhk, n, M), dtype=np.uint16)
+        lib().pq_encode_direct_u16(_p(X, ctypes.c_float), _p(cents, ctypes.c_float), _p(codes, ctypes.c_uint16),
+                                   bs * nhk * n, d, M, C)
+        return codes
     codes = np.empty((bs, nhk, n, M), dtype=np.uint8)
     lib().pq_encode_direct(_p(X, ctypes.c_float), _p(cents, ctypes.c_float), _p(codes, ctypes.c_uint8),
                            bs * nhk * n, d, M, C)
@@ -136,15 +146,16 @@ def pq_encode_numpy(X, cents) -> np.ndarray:
     bs, nhk, n, d = X.shape
     M, C, dm = cents.shape
     Xr = X.reshape(bs * nhk * n, M, 1, dm)
-    out = np.empty((bs * nhk * n, M), dtype=np.uint8)
-    step = 4096
+    dt = np.uint8 if C <= 256 else np.uint16
+    out = np.empty((bs * nhk * n, M), dtype=dt)
+    step = max(1, 4096 * 256 // C)
     for i0 in range(0, Xr.shape[0], step):
         e = Xr[i0:i0 + step] - cents[None]            # (v, M, C, dm) fp32
         sq = e * e
         acc = np.zeros(sq.shape[:-1], dtype=np.float32) + sq[..., 0]
         for k in range(1, dm):
             acc = acc + sq[..., k]
-        out[i0:i0 + step] = np.argmin(acc, axis=-1).astype(np.uint8)
+        out[i0:i0 + step] = np.argmin(acc, axis=-1).astype(dt)
     return out.reshape(bs, nhk, n, M)
 
 
@@ -165,8 +176,17 @@ def pq_encode_cdist_torch(X, cents):
 # decode (sa_decode_4d)
 # --------------------------------------------------------------------------------------------------
 def pq_decode(codes, cents) -> np.ndarray:
-    codes = _u8(codes)
     cents_f = _f32(cents)
+    if np.asarray(codes).dtype == np.uint16:
+        codes = np.ascontiguousarray(codes)
+        bs, nhk, n, M = codes.shape
+        Mc, C, dm = cents_f.shape
+        assert M == Mc
+        out = np.empty((bs, nhk, n, M * dm), dtype=np.float32)
+        lib().pq_decode_u16(_p(codes, ctypes.c_uint16), _p(cents_f, ctypes.c_float), _p(out, ctypes.c_float),
+                            bs * nhk * n, M * dm, M, C)
+        return out
+    codes = _u8(codes)
     bs, nhk, n, M = codes.shape
     Mc, C, dm = cents_f.shape
     assert M == Mc

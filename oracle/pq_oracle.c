@@ -98,6 +98,46 @@ void pq_decode(const uint8_t *codes, const float *cents, float *out,
         }
 }
 
+/* ---- nbits 9..16: uint16 codes (reference nbits2dtype, pq_utils.py:542-552; sa_encode_4d(_keops) casts the argmin
+ * indices with `.to(target_dtype)`, :449/:499; sa_decode_4d widens any code dtype to long, :525).  Same arithmetic and
+ * tie rule as pq_encode_direct, C up to 65536. */
+void pq_encode_direct_u16(const float *X, const float *cents, uint16_t *codes,
+                          int64_t n_vec, int d, int M, int C)
+{
+    const int dm = d / M;
+    for (int64_t i = 0; i < n_vec; ++i) {
+        const float *x = X + i * (int64_t)d;
+        for (int m = 0; m < M; ++m) {
+            const float *xm = x + m * dm;
+            const float *cm = cents + (int64_t)m * C * dm;
+            float best = INFINITY;
+            int best_c = 0;
+            for (int c = 0; c < C; ++c) {
+                const float *cc = cm + c * dm;
+                float acc = 0.0f;
+                for (int k = 0; k < dm; ++k) {
+                    volatile float e = xm[k] - cc[k];
+                    volatile float sq = e * e;
+                    acc = acc + sq;
+                }
+                if (acc < best) { best = acc; best_c = c; }
+            }
+            codes[i * (int64_t)M + m] = (uint16_t)best_c;
+        }
+    }
+}
+
+void pq_decode_u16(const uint16_t *codes, const float *cents, float *out,
+                   int64_t n_vec, int d, int M, int C)
+{
+    const int dm = d / M;
+    for (int64_t i = 0; i < n_vec; ++i)
+        for (int m = 0; m < M; ++m) {
+            const float *cc = cents + ((int64_t)m * C + codes[i * (int64_t)M + m]) * dm;
+            for (int k = 0; k < dm; ++k) out[i * (int64_t)d + m * dm + k] = cc[k];
+        }
+}
+
 /* ---- decode-step attention, fp64 accumulation (the gold) --------------------------------------
  * q        (bs, nh, d) fp32
  * k_codes  (bs, nh_k, T, M) u8 ; v_codes (bs, nh_k, T, M) u8   (row-major, Interface.template.cu:29-30)

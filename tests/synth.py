@@ -55,5 +55,13 @@ GOLDEN_ENCODE = [
     ("n100_d64_m16_c128", 205, 1, 2, 100, 64, 16, 128),
 ]
 
+# nbits 9..12 (uint16 codes, reference nbits2dtype pq_utils.py:542-552): sa_encode_4d(target_dtype=uint16) outputs.
+GOLDEN_ENCODE_U16 = [
+    # name,          seed, bs, nh_k, n,  d,   M,  C
+    ("u16_n40_c512",   211, 1,  2,   40, 128, 64, 512),
+    ("u16_n33_c1024_m32", 212, 2, 1, 33, 128, 32, 1024),
+    ("u16_n20_c4096",  213, 1,  1,   20, 128, 64, 4096),
+]
+
 # Large encode case: only a SHA-256 of the reference codes and the list of disagreeing positions.
 GOLDEN_ENCODE_BIG = ("cfg1_n4096", 42, 1, 8, 4096, 128, 64, 256)

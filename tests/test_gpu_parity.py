@@ -666,3 +666,105 @@ def test_ragged_batch_device_lengths(Tmax, nh, nhk, env, oracle):
         cb = {k: (v[b:b + 1] if isinstance(v, np.ndarray) and v.shape[0] == bs else v) for k, v in c.items()}
         cb["k_codes"], cb["v_codes"], cb["r"] = cb["k_codes"][:, :, :Ts[b]], cb["v_codes"][:, :, :Ts[b]], rs_[b]
         _check(o[b:b + 1], oracle.decode_attn(**cb), f"batch item {b} (T={Ts[b]}, r={rs_[b]})")
+
+
+# ---- every BASELINE.json config at its own shape (configs_untested) -----------------------------------
+def test_baseline_config1_llama2_7b_4k(env, oracle):
+    """configs[1]: Llama-2-7B-hf, 4K context, PQ M=64 nbits=8, batch 1: nh = nh_k = 32 (MHA, G = 1), T = 4096.
+    Through the reference's three layouts: 10-arg row-major, fully paged, 13-arg row-major K + paged V."""
+    torch, ops = env
+    c = synth.attn_case(2201, 1, 32, 32, 128, 64, 256, 4096, 17)
+    gold = oracle.decode_attn(**c)
+    _check(_run_rowmajor(torch, ops, c, 64, 256), gold, "cfg1 rowmajor")
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, "cfg1 paged")
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64, k_paged=False, i64=True), gold, "cfg1 mixed")
+
+
+def test_baseline_config3_per_gpu_shape(env, oracle):
+    """configs[3] per GPU: Llama-3.1-8B, 32K context, 16 requests over 8 GPUs = batch 2 per GPU: bs = 2, nh = 32,
+    nh_k = 8, T = 32768, M = 64, PagedPQCache layout (paged K and V), fused append, device-resident lengths; two
+    consecutive decode steps (the second reads the row the first one parked)."""
+    torch, ops = env
+    bs, nh, nhk, ps, cap, T, r0, start = 2, 32, 8, 64, 128, 32768, 100, 40
+    c = synth.attn_case(2203, bs, nh, nhk, 128, 64, 256, T, cap)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    perm = np.random.RandomState(6).permutation(vpool.shape[0])
+    vpool, kpool, ids = vpool[perm], kpool[perm], np.argsort(perm)[ids]
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    kc, vc = torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda()
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    lengths = torch.tensor([[T, r0, start, 0]] * bs, dtype=torch.int32, device="cuda")
+    rs = np.random.RandomState(10)
+    k_hist, v_hist = c["k_res"].copy(), c["v_res"].copy()
+    r = r0
+    for step in range(2):
+        k_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        v_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0, M=64, C=256, resid_start=start, dev_lengths=lengths,
+                                 k_new=torch.from_numpy(k_new).cuda(), v_new=torch.from_numpy(v_new).cuda(),
+                                 k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T + 2 * cap)
+        torch.cuda.synchronize()
+        k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
+        r += 1
+        _check(out.cpu().numpy(), oracle.decode_attn(**dict(c, k_res=k_hist, v_res=v_hist, r=r)), f"cfg3 step {step}")
+    assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
+
+
+def test_baseline_config4_128k_m32(env, oracle):
+    """configs[4]: Llama-3.1-8B, 128K context, PQ M=32 nbits=8, batch 1: nh = 32, nh_k = 8, T = 131072, paged."""
+    torch, ops = env
+    c = synth.attn_case(2204, 1, 32, 8, 128, 32, 256, 131072, 77)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, 32, 256, 64), gold, "cfg4 paged")
+    _check(_run_paged(torch, ops, oracle, c, 32, 256, 64, k_paged=False, i64=True, shuffle=False), gold, "cfg4 mixed")
+
+
+def test_kernel_registry_get_kernel(env, oracle):
+    """KernelRegistry.get_kernel(l) (pq_utils.py:43-96): resolves the binding by the Ns that l2Ns(l) picks, owns the
+    (bs=1, nh, Ns+1, ...) partial buffers, returns the 8-arg closure DynamicPQCache.decoding calls (:315-325)."""
+    torch, ops = env
+    from million_amd.pq_cache import KernelRegistry, l2Ns
+    nh, d, M, C = 8, 128, 64, 256
+    reg = KernelRegistry(M=M, d=d, nbits=8, nh=nh, scalar_t=torch.float16, device="cuda")
+    for l in (64, 65, 129, 257, 2049):
+        r = 17
+        c = synth.attn_case(300 + l, 1, nh, nh, d, M, C, l - r, r)
+        t = _dev(torch, c)
+        k = reg.get_kernel(l)
+        Ns = l2Ns(l)
+        assert k is reg.get_kernel(l) and set(reg.kernels) >= {Ns}
+        assert reg.partial_out_buffers[Ns].shape == (1, nh, Ns + 1, d) and reg.partial_lse_buffers[Ns].shape == (1, nh, Ns + 1)
+        out = k(t["q"], t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"], t["v_res"], r)
+        _check(out.cpu().numpy(), oracle.decode_attn(**c), f"registry l={l} Ns={Ns}")
+    assert sorted(reg.kernels) == [1, 2, 4, 16, 32]
+    with pytest.raises(NotImplementedError):
+        KernelRegistry(M=M, d=d, nbits=12, nh=nh).get_kernel(100)
+
+
+def test_dynamic_cache_decoding_through_registry(env, oracle):
+    """DynamicPQCache.decoding(fused=False): the reference's call sequence (window copy, then the kernel that
+    KernelRegistry.get_kernel(seen_tokens) resolved from `bindings`) gives the same output as the fused launch."""
+    torch, ops = env
+    from million_amd.pq_cache import DynamicPQCache
+    bs, nh, nhk, d, M, C = 1, 8, 2, 128, 64, 256
+    rs = np.random.RandomState(13)
+    ck = torch.from_numpy(rs.standard_normal((M, C, 2)).astype(np.float16)).cuda()
+    n_prompt, n_dec = 70, 140
+    K = torch.from_numpy(rs.standard_normal((bs, nhk, n_prompt + n_dec, d)).astype(np.float16)).cuda()
+    V = torch.from_numpy(rs.standard_normal((bs, nhk, n_prompt + n_dec, d)).astype(np.float16)).cuda()
+    Q = torch.from_numpy(rs.standard_normal((n_dec, bs, nh, 1, d)).astype(np.float16)).cuda()
+    outs = {}
+    for fused in (True, False):
+        cache = DynamicPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, max_tokens=512)
+        cache.set_cent(ck, ck)
+        cache.prefill(Q[0].repeat(1, 1, n_prompt, 1), K[:, :, :n_prompt].contiguous(), V[:, :, :n_prompt].contiguous(), 0)
+        o = [cache.decoding(Q[i], K[:, :, n_prompt + i:n_prompt + i + 1].contiguous(),
+                            V[:, :, n_prompt + i:n_prompt + i + 1].contiguous(), 0, fused=fused) for i in range(n_dec)]
+        outs[fused] = torch.stack(o).float().cpu().numpy()
+        if not fused:
+            assert sorted(cache.registery.kernels) == [2, 4]      # l2Ns(71..128) = 2, l2Ns(129..210) = 4
+    assert np.abs(outs[True] - outs[False]).max() < 2e-3

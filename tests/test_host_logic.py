@@ -100,6 +100,50 @@ def test_multirank_timing_gloo():
     assert s0 + s1 == list(range(5))
 
 
+def test_bench_launcher_spawns_ranks_dry_cpu():
+    """`python bench.py --gpus 2 --dry-cpu`: with no WORLD_SIZE in the environment bench.py re-launches itself under
+    torch.distributed.run with 2 ranks (gloo here, RCCL on the GPU box) and rank 0 prints ONE JSON line whose n_gpus
+    comes from dist.get_world_size() and whose ranks_seen comes from an all-gather over the job's backend; with --gpus
+    > 1 the default is BASELINE configs[3]'s 2 requests per GPU."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-cpu", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["scaling"] == "weak"
+    assert [x[0] for x in rec["config"]["ranks_seen"]] == [0, 1]
+    assert rec["config"]["batch_per_gpu"] == 2
+    # rank 1's step sleeps twice as long: the job time is rank 1's, the value counts both ranks' requests
+    assert rec["ms_per_step"] >= 4.0 * 0.9 and rec["value"] == pytest.approx(2 * 2 * 1000.0 / rec["ms_per_step"], rel=1e-3)
+
+
+def test_bench_window_fill_puts_a_flush_in_the_timed_region():
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    for warmup, steps in ((5, 20), (8, 64), (0, 1), (3, 200), (100, 10)):
+        r = B.window_fill_at_start(128, warmup, steps)
+        assert 1 <= r <= 128
+        # simulate the window: flush (r -= 64) at the start of a step that finds r >= 128, then append
+        flushes = []
+        for i in range(warmup + steps):
+            if r >= 128:
+                r -= 64
+                flushes.append(i - warmup)
+            r += 1
+        assert any(0 <= f < steps for f in flushes), (warmup, steps, flushes)
+    assert B.parse(["--gpus", "8"]).batch_per_gpu == 2 and B.parse([]).batch_per_gpu == 1
+    assert B.parse(["--gpus", "8", "--batch-per-gpu", "1"]).batch_per_gpu == 1
+
+
 def test_harness_fp16_backends_agree_cpu():
     """million_amd/harness.py: the HF-recipe baseline (torch.cat + repeat_kv + SDPA, modeling_llama.py:403-443)
     and the preallocated GQA-view baseline are the same attention; tiny shape, CPU, fp32 weights."""

@@ -90,7 +90,20 @@ def main():
                             params=np.array([seed, bs, nhk, n, d, M, C], dtype=np.int64))
         print("encode", name, tuple(codes.shape))
 
-    # ---- big encode case: hash + (filled by the test) ----
+    # ---- nbits 9..12: uint16 codes (nbits2dtype(nbits), pq_utils.py:542-552, as main_pq.py passes it) ----
+    for (name, seed, bs, nhk, n, d, M, C) in synth.GOLDEN_ENCODE_U16:
+        c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+        X, cents = torch.from_numpy(c["X"]).float(), torch.from_numpy(c["cents"]).float()
+        nbits = int(np.log2(C))
+        assert R.nbits2dtype(nbits) == torch.uint16
+        codes = R.sa_encode_4d(X, cents, target_dtype=R.nbits2dtype(nbits))
+        dec = R.sa_decode_4d(codes, cents)
+        np.savez_compressed(out_dir / f"encode_{name}.npz", codes=codes.numpy().astype(np.uint16),
+                            decoded=dec.numpy().astype(np.float16),
+                            params=np.array([seed, bs, nhk, n, d, M, C], dtype=np.int64))
+        print("encode", name, tuple(codes.shape), codes.dtype)
+
+    # ---- big encode case: hash + the reference's code values where the two forms disagree ----
     (name, seed, bs, nhk, n, d, M, C) = synth.GOLDEN_ENCODE_BIG
     c = synth.encode_case(seed, bs, nhk, n, d, M, C)
     X, cents = torch.from_numpy(c["X"]).float(), torch.from_numpy(c["cents"]).float()
@@ -106,6 +119,10 @@ def main():
         "n_codes": int(codes.size), "n_diff_cdist_vs_direct": int(diff.shape[0]),
         "diff_positions": diff.tolist()[:64],
         "diff_gaps": [float(gap[tuple(p)]) for p in diff[:64]],
+        # the reference's (cdist-form) code at each disagreeing position: patching them into the direct-form codes
+        # must reproduce sha256_reference_cdist_codes (tests/test_oracle.py)
+        "diff_reference_codes": [int(codes[tuple(p)]) for p in diff[:64]],
+        "diff_direct_codes": [int(direct[tuple(p)]) for p in diff[:64]],
     }
     print("encode big:", manifest["encode_big"]["n_diff_cdist_vs_direct"], "of", codes.size, "differ")
     (out_dir / "manifest.json").write_text(json.dumps(manifest, indent=1))
