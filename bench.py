@@ -177,7 +177,7 @@ def main():
         dl_backup = [t.clone() for t in cache.lengths]
         step_eager(True)                       # eager once: allocates the workspace, warms caches
         torch.cuda.synchronize()
-        for name, r_cap in (("plain", r0), ("flush", cap)):
+        for name, r_cap in (("plain", min(r0, cap - 1)), ("flush", cap)):
             cache.set_host_state((st[0], [r_cap] * layers, st[2], st[3]))
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):

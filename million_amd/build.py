@@ -37,11 +37,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
-    if os.environ.get("MILLION_SAVE_TEMPS"):
+    cwd = CSRC
+    if os.environ.get("MILLION_SAVE_TEMPS"):      # ISA / IR dumps go to scratch (gpurun_out/ never ships to the GPU box)
+        cwd = HERE.parent / "gpurun_out" / "save_temps"
+        cwd.mkdir(parents=True, exist_ok=True)
         cmd.insert(1, "-save-temps")
     if verbose:
         print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, cwd=str(CSRC), capture_output=True, text=True)
+    r = subprocess.run(cmd, cwd=str(cwd), capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed building libmillion_hip.so")

@@ -173,11 +173,8 @@ int launch_attn_generic(const AttnParams &p, hipStream_t s) {
                                         kGenBlock + 8 + p.d) + 16;
     if (kGenBlock % p.d != 0) { set_error("generic kernel: d=%d must divide %d", p.d, kGenBlock); return MILLION_ERR_SHAPE; }
     if (lds > 160 * 1024) { set_error("generic kernel: LUT of M*C=%d floats does not fit LDS", p.M * p.C); return MILLION_ERR_SHAPE; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *)attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (device_once(0))
+        (void)hipFuncSetAttribute((const void *)attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     dim3 grid(p.nsplit + 1, p.bs * p.nh_k);
     hipLaunchKernelGGL(attn_generic_kernel, grid, dim3(kGenBlock), lds, s, p);
     const hipError_t e = hipGetLastError();

@@ -671,10 +671,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     }
     if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4), after q and the table have been requested
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
-    int T = dl[0] < p.T ? dl[0] : p.T;     // the host value is the bound the grid was sized for
-    const int r_old = dl[1], rstart = dl[2];
+    int T = dl[0], r_old = dl[1], rstart = dl[2];
+    clamp_lengths(p, T, r_old, rstart);            // T <= the host bound the grid was sized for; r, start inside the window
     const int r = r_old + (p.k_new ? 1 : 0);       // fused append: the new token is window row r_old
-    if (T < 1) T = 0;
     // The T tokens that are actually there (device-resident lengths: the host sized the grid for its BOUND on T) are
     // dealt to the nsplit splits in whole 32-token units, as evenly as units allow: the first (units % nsplit) splits
     // carry one unit more.  (Uniform split lengths rounded up to a page left the last splits short or empty and made
@@ -1034,10 +1033,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
     }
     if (p.dev_lengths)
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
-    int T = dl[0] < p.T ? dl[0] : p.T;
-    const int r_old = dl[1], rstart = dl[2];
-    const int r = r_old + (p.k_new ? 1 : 0);
-    if (T < 1) T = 0;
+    int T = dl[0], r_old = dl[1], rstart = dl[2];
+    clamp_lengths(p, T, r_old, rstart);            // T <= the host bound the grid was sized for; r, start inside the window
+    const int r = r_old + (p.k_new ? 1 : 0);       // fused append: the new token is window row r_old
     // The T tokens that are actually there (device-resident lengths: the host sized the grid for its BOUND on T) are
     // dealt to the nsplit splits in whole 32-token units, as evenly as units allow: the first (units % nsplit) splits
     // carry one unit more.  (Uniform split lengths rounded up to a page left the last splits short or empty and made
@@ -1237,6 +1235,316 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams 
 #undef STAMP
 }
 
+// =====================================================================================================
+// Streaming kernel: the pipelined schedule for ANY split length (M = 64).
+//
+// What changed against attn_mfma_pipe_kernel (which it replaces on every shape it covers):
+//   * units are dealt to (split, wave) by PAGE, strided: page (j * ppr + wave / upp) * nsplit + split goes to round j of
+//     the wave (upp = units per page, ppr = 8 / upp pages per workgroup and round), so where a wave reads does not depend
+//     on the context length T - only HOW MANY units it has does.  The page ids of a wave's first 64 rounds are ONE
+//     vector load (lane = round) issued as the first instruction; each unit's id is then a v_readlane.  No scalar-cache
+//     round trip sits between the kernel start and the first code request, device-resident lengths included
+//     (attn_mfma_pipe_kernel: lengths -> split range -> page ids -> codes, two dependent s_load round trips);
+//   * the block "values of unit j | scores of unit j + 1" repeats for as many units as the wave has, the ring slot of
+//     unit j refilled with unit j + 4 right behind it (never in a conditional: rounds past the last unit re-read it), so a
+//     split of 8, 16 or 128 units per wave runs the same interleaved schedule (batch >= 2, 128K contexts);
+//   * whole pages belong to one wave pair, so rows past T - 1 of the last unit stay inside an allocated page: no row
+//     clamping on paged K.
+// MODE 0: K and V paged, int32 ids (PagedPQCache).  MODE 1: row-major K, V in dense scratch pages (the reference's
+// 10-arg layout after the transpose).  MODE 2: anything else, by run-time flags.
+// =====================================================================================================
+template <int MODE>
+__global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int bh = blockIdx.y;
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int G = p.G;
+    const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
+    const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
+    const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i dl = {p.T, p.r, p.rstart, 0};
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const bool dbg_on = p.dbg != nullptr;
+#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
+    stamp_lds_clear(dbg_on, lane, wave);
+    STAMP(0);
+    const int q4 = lane >> 4, c16 = lane & 15;
+
+    // ---- where this wave reads: page pg0 + j * pg_step in round j, tokens [tin, tin + 32) of it ----
+    const int ups = p.ps_shift - 5;                       // log2(units per page)
+    const int wp = wave >> ups, uw = wave & ((1 << ups) - 1);
+    const int pg0 = wp * p.nsplit + split;
+    const int pg_step = p.nsplit << (3 - ups);
+    const int tin = uw << 5;
+    // page ids of rounds 0..63 (lane = round), the oldest loads of the wave
+    int vpk = 0, vpv = 0;
+    {
+        int pgl = pg0 + lane * pg_step;
+        pgl = pgl < p.n_pages_cap ? pgl : p.n_pages_cap - 1;
+        const long long idx = (long long)bh * p.n_pages_cap + pgl;
+        if (k_paged) vpk = ids64 ? (int)p.k_ids64[idx] : p.k_ids32[idx];
+        if (v_ident) vpv = (int)idx;
+        else vpv = ids64 ? (int)p.v_ids64[idx] : p.v_ids32[idx];
+    }
+    v8f16 qb[4];
+    {
+        const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            v4u t = *(const v4u *)(qv + 8 * s);
+            if (c16 >= G) t = v4u{0, 0, 0, 0};
+            qb[s] = __builtin_bit_cast(v8f16, t);
+        }
+    }
+    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
+    h2 new_k = {}, new_v = {};
+    if (append_wave) {
+        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
+    }
+    v4u tabk[8], tabv[8];
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
+    {
+        const v4u *ks = (const v4u *)p.k_tab;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+    }
+    if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4); only the masks and the window depend on it
+        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
+    int T = dl[0], r_old = dl[1], rstart = dl[2];
+    clamp_lengths(p, T, r_old, rstart);
+    const int r = r_old + (p.k_new ? 1 : 0);
+    const int t0 = (pg0 << p.ps_shift) + tin;             // first token of round 0
+    const int t_step = pg_step << p.ps_shift;             // tokens between rounds
+    const int n_mine = T > t0 ? (T - t0 + t_step - 1) / t_step : 0;      // rounds (= units) of this wave; host: <= 64
+    const int j_last = n_mine > 0 ? n_mine - 1 : 0;
+    const int T_ld = T > 0 ? T : 1;
+
+    // ---- one unit's four 16-byte requests into ring slot SL; J is wave-uniform; rounds past the wave's last unit
+    //      re-request that unit (L2 hits, never consumed), so that no code load sits in a conditional ----
+    UnitCodes ring[kRing];
+    const unsigned k_lane_off = ((unsigned)c16 << 6) + 16u * q4;                       // row c16 (+16 for g2 = 1), quarter q4
+    const unsigned v_lane_off = ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
+#define UNIT_REQ(SL, J)                                                                                            \
+    {                                                                                                              \
+        const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
+        const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
+        gptr_u8 kb_;                                                                                               \
+        if (k_paged) {                                                                                             \
+            const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
+            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << 6));                                     \
+            ring[SL].k[0] = *(gptr_v4u)(kb_ + k_lane_off);                                                         \
+            ring[SL].k[1] = *(gptr_v4u)(kb_ + k_lane_off + 1024u);                                                 \
+        } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
+            const int tu_ = t0 + jc_ * t_step;                                                                     \
+            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
+            ring[SL].k[0] = *(gptr_v4u)(kb_ + (((unsigned)min(tu_ + c16, T_ld - 1) << 6) + 16u * q4));             \
+            ring[SL].k[1] = *(gptr_v4u)(kb_ + (((unsigned)min(tu_ + c16 + 16, T_ld - 1) << 6) + 16u * q4));        \
+        }                                                                                                          \
+        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (6 + p.ps_shift)) + tin);                              \
+        ring[SL].v[0] = *(gptr_v4u)(vb_ + v_lane_off);                                                             \
+        ring[SL].v[1] = *(gptr_v4u)(vb_ + v_lane_off + (32u << p.ps_shift));                                       \
+    }
+    UNIT_REQ(0, 0)
+    {
+        const v4u *ks = (const v4u *)p.k_tab;
+#pragma unroll
+        for (int i = 4; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+    }
+    UNIT_REQ(1, 1)
+
+    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
+    const bool has_res = wave < rcnt;
+    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    ResTile rt;
+    if (has_res) load_res_tile(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+    STAMP(7);
+    {
+        v4u *ld = (v4u *)smem;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabk[i];
+    }
+    STAMP(8);
+    __syncthreads();
+    STAMP(1);
+
+    float m_run = -INFINITY, l_run = 0.f;
+    v16f32 O[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
+    if (append_wave) {
+        int row_n = rstart + r_old;
+        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
+        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
+        *(h2 *)(p.k_res_w + o) = new_k;
+        *(h2 *)(p.v_res_w + o) = new_v;
+    }
+    if (has_res) {      // residual tile of this wave first: it needs neither codebook
+        float scr[4];
+        score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
+        softmax_online<4>(scr, m_run, l_run, O, G, lane);
+        value_res_tile(rt, scr, O);
+    }
+    STAMP(2);
+
+    const unsigned kbase = (unsigned)q4 * 16u * 1024u;
+    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);
+    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);
+
+    unsigned a[2][4], e[2][8], P[2][4];
+    float sc[8];
+#define KG(SL, ST) k_gather(ring[SL].k[(ST) >> 2][(ST) & 3], kbase + ((ST) & 3) * 4096, a[(ST) & 1])
+#define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
+        as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
+#define VG(SL, I) v_gather(ring[SL].v, I, vconst0, vconst1, e[(I) & 1])
+#define VS(I) v_step(e[(I) & 1], P[(I) & 1], O[(I) >> 1])
+    // raw scores of round J out of the accumulators; only the unit that holds token T - 1 (wave-uniform) is masked; a
+    // round whose first token is past T - 1 (only the prologue of a wave without whole rounds meets one) gives -inf
+#define SCORES_OUT(J)                                                                                              \
+    {                                                                                                              \
+        const int t_u = t0 + (J) * t_step;                                                                         \
+        if (t_u + 32 <= T) {                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[i] = D[i >> 2][i & 3];                                \
+        } else {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+                sc[i] = t_u + 16 * (i >> 2) + 4 * q4 + (i & 3) < T ? D[i >> 2][i & 3] : -INFINITY;                 \
+        }                                                                                                          \
+    }
+    // BLOCK: the 4 value steps of the unit in slot U4 (round J) interleaved with the 8 score stages of the unit in slot
+    // U4 + 1 (round J + 1); then the first gathers of the next block, the online softmax of round J + 1 and the refill
+    // of slot U4 with round J + 4.
+#define BLOCK(U4, J)                                                                                               \
+    {                                                                                                              \
+        v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            VS(i);                                                                                                 \
+            if (i < 3) VG(U4, i + 1);                                                                              \
+            KM(2 * i);                                                                                             \
+            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 2);                                                              \
+            KM(2 * i + 1);                                                                                         \
+            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 3);                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+        VG(((U4) + 1) & 3, 0);                                                                                     \
+        KG(((U4) + 2) & 3, 0);                                                                                     \
+        KG(((U4) + 2) & 3, 1);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        UNIT_REQ(U4, (J) + 4)                                                                                      \
+        SCORES_OUT((J) + 1)                                                                                        \
+        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
+        value_prep(sc, P);                                                                                         \
+    }
+#define VALUE_ALONE(U4)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        if (i < 3) VG(U4, i + 1);                                                                                  \
+        VS(i);                                                                                                     \
+    }
+    // One unit on its own (the up to three units a wave has beyond its whole rounds of four): scores, softmax, values,
+    // self-contained, so that the branch around it carries no pipeline state.
+#define SINGLE(SL, J)                                                                                              \
+    {                                                                                                              \
+        v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
+        KG(SL, 0);                                                                                                 \
+        KG(SL, 1);                                                                                                 \
+        _Pragma("unroll") for (int st = 0; st < 8; ++st) {                                                         \
+            KM(st);                                                                                                \
+            if (st + 2 < 8) KG(SL, st + 2);                                                                        \
+        }                                                                                                          \
+        SCORES_OUT(J)                                                                                              \
+        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
+        value_prep(sc, P);                                                                                         \
+        VG(SL, 0);                                                                                                 \
+        VALUE_ALONE(SL)                                                                                            \
+    }
+    const int n_whole = n_mine >> 2, n_rem = n_mine & 3;      // whole rounds of four units + up to three more
+    {
+        // prologue: the 8 score stages of round 0 (masked out when the wave has no whole round: its units are all
+        // handled as single units below); the V codebook and round 2 are requested in between
+        {
+            const v4u *vs = (const v4u *)p.v_tab_col;
+            v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            KG(0, 0);
+            KG(0, 1);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st < 4) {
+                    tabv[2 * st] = vs[((2 * st + rot) & 7) * (kNW * 64) + tid];
+                    tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & 7) * (kNW * 64) + tid];
+                }
+                KM(st);
+                if (st + 2 < 8) KG(0, st + 2);
+                if (st == 4) UNIT_REQ(2, 2)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            SCORES_OUT(0)
+            if (n_whole == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sc[i] = -INFINITY;
+            }
+        }
+        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);
+        value_prep(sc, P);
+        STAMP(16);
+        {
+            v4u *ldv = (v4u *)(smem + kVBase);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ldv[((i + rot) & 7) * (kNW * 64) + tid] = tabv[i];
+        }
+        STAMP(12);
+        __syncthreads();
+        STAMP(13);
+        UNIT_REQ(3, 3)
+        if (n_whole > 0) {
+            VG(0, 0);
+            KG(1, 0);
+            KG(1, 1);
+            int j = 0;
+            for (int w = 1; w < n_whole; ++w) {
+                BLOCK(0, j)
+                ++j;
+                BLOCK(1, j)
+                ++j;
+                BLOCK(2, j)
+                ++j;
+                BLOCK(3, j)
+                ++j;
+                if (w == 1) STAMP(17);
+            }
+            BLOCK(0, j)
+            BLOCK(1, j + 1)
+            BLOCK(2, j + 2)
+            STAMP(19);
+            VALUE_ALONE(3)
+        }
+        // the units beyond the whole rounds sit in ring slots 0..2 (requested by the last round's refills, or up front)
+        if (n_rem > 0) SINGLE(0, 4 * n_whole)
+        if (n_rem > 1) SINGLE(1, 4 * n_whole + 1)
+        if (n_rem > 2) SINGLE(2, 4 * n_whole + 2)
+    }
+#undef SINGLE
+#undef KG
+#undef KM
+#undef VG
+#undef VS
+#undef SCORES_OUT
+#undef BLOCK
+#undef VALUE_ALONE
+#undef UNIT_REQ
+    STAMP(3);
+    merge_and_publish(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
+#undef STAMP
+}
+
 // Self-check of the row-swap reductions (tests/test_gpu_parity.py): one wave, in[64] -> max / sum over the
 // four 16-lane rows per column.
 __global__ void rows_reduce_check_kernel(const float *in, float *out_max, float *out_sum) {
@@ -1258,21 +1566,15 @@ bool attn_mfma_supported(const AttnParams &p) {
     return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
 }
 
-// A/B knob (million_set_force_generic 2 / 3): 0 = auto, 1 = grouped kernel only, 2 = double the splits when that
-// brings a split into the pipelined kernel's range (two rounds of workgroups per CU)
+// A/B knob (million_set_force_generic 2 / 3): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only,
+// 2 = the round-1 choice (pipelined 4-unit kernel for splits of 25..40 units, grouped kernel otherwise)
 static int g_mfma_policy = 0;
 void set_mfma_policy(int policy) { g_mfma_policy = policy; }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     AttnParams p = p_in;
-    // split policy: about one workgroup per CU; a split is a multiple of 64 tokens, at least 512 long
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    // split policy: about one workgroup per CU; a split is at least 512 tokens long
+    const int cus = device_cus();
     const int bh = p.bs * p.nh_k;
     int ns = (cus + bh - 1) / bh;
     if (ns > kMaxSplits) ns = kMaxSplits;
@@ -1283,27 +1585,32 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     const int units = p.T > 0 ? (p.T + 31) / 32 : 1;
     if (ns > units) ns = units;
     int len = 32 * ((units + ns - 1) / ns);
-    if (g_mfma_policy == 2 && len > 40 * 32 && 2 * ns <= kMaxSplits) {
-        const int len2 = 32 * ((units + 2 * ns - 1) / (2 * ns));
-        if (len2 > 24 * 32 && len2 <= 40 * 32) { len = len2; ns = 2 * ns; }
-    }
     p.nsplit = ns;
     p.nslots = ns;
     p.split_len = len;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (device_once(1)) {
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = true;
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
-    // the pipelined kernel (M = 64) runs every wave through 4 units (+ a fifth where it exists): splits of 25..40 units
+    // streaming kernel: rounds per wave = ceil(T / (ns * 256 tokens)) must fit the 64 page ids a wave preloads
+    const bool stream_ok = p.M == 64 && p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64;
     if (p.M == 32) {
         if (p.T > 0) hipLaunchKernelGGL((attn_mfma_kernel<true, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_mfma_kernel<false, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
-    } else if (g_mfma_policy != 1 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
+    } else if (g_mfma_policy == 0 && stream_ok) {
+        if (p.k_paged && !p.v_identity && !p.ids64)
+            hipLaunchKernelGGL(attn_stream_kernel<0>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+        else if (!p.k_paged && p.v_identity)
+            hipLaunchKernelGGL(attn_stream_kernel<1>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+        else
+            hipLaunchKernelGGL(attn_stream_kernel<2>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
+    } else if (g_mfma_policy == 2 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
         hipLaunchKernelGGL(attn_mfma_pipe_kernel, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else if (p.T > 0)
         hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);

@@ -63,12 +63,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Device-resident lengths are not trusted: T is clamped to the host bound the grid was sized for, r to the window
+// capacity (minus the row a fused append is about to add), the ring start to [0, cap).  Out-of-range values become a
+// shorter context / window, never an out-of-bounds read.
+__device__ __forceinline__ void clamp_lengths(const AttnParams &p, int &T, int &r, int &rstart) {
+    T = T < 0 ? 0 : (T > p.T ? p.T : T);
+    const int rmax = p.rcap - (p.k_new ? 1 : 0);
+    r = r < 0 ? 0 : (r > rmax ? rmax : r);
+    rstart = (unsigned)rstart < (unsigned)p.rcap ? rstart : 0;
+}
 __device__ __forceinline__ void load_lengths(const AttnParams &p, int b, int &T, int &r, int &rstart) {
     if (p.dev_lengths) {
         T = p.dev_lengths[b * 4 + 0];
         r = p.dev_lengths[b * 4 + 1];
         rstart = p.dev_lengths[b * 4 + 2];
-        if (T > p.T) T = p.T;   // host value is the bound the grid was sized for
+        clamp_lengths(p, T, r, rstart);
     } else {
         T = p.T; r = p.r; rstart = p.rstart;
     }
@@ -312,6 +321,11 @@ bool attn_mfma_shape_ok(const AttnParams &p);
 int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hipStream_t s);
 bool attn_mfma_supported(const AttnParams &p);
 void set_error(const char *fmt, ...);
+
+// Per-device facts and one-time per-device setup (one process may drive several devices): CU count, and a set of
+// "dynamic-LDS attribute already raised on this device" bits, one per kernel family.  Guarded by a mutex.
+int device_cus();
+bool device_once(int family);      // true exactly once per (current device, family 0..7)
 
 void set_mfma_policy(int policy);   // attn_mfma.hip: A/B knob behind million_set_force_generic(2 / 3)
 

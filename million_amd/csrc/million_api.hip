@@ -3,11 +3,15 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace million {
 
 static thread_local char g_err[512] = "";
+// Diagnostic knobs (million_set_force_generic, million_debug_set_stamp_buffer): process-wide, plain words, meant to be
+// set from one thread before the calls they affect (A/B runs and the stamp profiler); not part of the product path.
 static int g_force_generic = 0;
 static unsigned long long *g_dbg = nullptr;
 
@@ -18,17 +22,37 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-static int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
+// ---- per-device state: the only mutable globals of the library besides the diagnostic knobs below ----
+constexpr int kMaxDevices = 64;
+static std::mutex g_dev_mutex;
+static int g_dev_cus[kMaxDevices];            // 0 = not queried yet
+static unsigned g_dev_once[kMaxDevices];      // bit f: family f has been set up on this device
+
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
 }
+int device_cus() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    if (g_dev_cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        g_dev_cus[dev] = n > 0 ? n : 256;
+    }
+    return g_dev_cus[dev];
+}
+bool device_once(int family) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    const unsigned bit = 1u << family;
+    if (g_dev_once[dev] & bit) return false;
+    g_dev_once[dev] |= bit;
+    return true;
+}
+static int num_cus() { return device_cus(); }
 
 // ---- prepare_cents: (M, C, dm) -> fp16 row image [m][c][dm], fp16 col image [c][m][dm], fp32 row image ----
 __global__ void prepare_cents_kernel(const f16 *__restrict__ src, f16 *__restrict__ dst, int M, int C, int dm) {

@@ -706,7 +706,7 @@ def test_baseline_config3_per_gpu_shape(env, oracle):
         v_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
         out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0, M=64, C=256, resid_start=start, dev_lengths=lengths,
                                  k_new=torch.from_numpy(k_new).cuda(), v_new=torch.from_numpy(v_new).cuda(),
-                                 k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T + 2 * cap)
+                                 k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T)
         torch.cuda.synchronize()
         k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
         r += 1
