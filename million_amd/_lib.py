@@ -3,10 +3,13 @@ or fails to load, importing the ops raises — the product path never runs on a 
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "libmillion_hip.so"
+if os.environ.get("MILLION_HIP_LIB"):      # development A/B builds (tools/ab_build.py); the product path uses the in-tree library
+    LIB_PATH = Path(os.environ["MILLION_HIP_LIB"]).resolve()
 
 c_i32, c_i64, c_u32, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t
 

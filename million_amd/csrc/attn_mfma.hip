@@ -23,9 +23,10 @@
 //   * the residual window (r <= 128 fp16 rows) is dealt round-robin to the splits and, inside a split, to its
 //     waves: each wave's rows are ONE 16-row MFMA tile (scores: A = the fp16 K rows; values: B = the fp16 V rows)
 //     that rides along with the wave's code units - no separate partial, no scalar FMA loop.
-//   * two kernels share everything above and the merge tail: attn_mfma_kernel (groups of 4 units: score pass,
-//     softmax, value pass; any split length) and attn_mfma_pipe_kernel (splits of 25..40 units: value steps of
-//     unit u interleaved with the score stages of unit u + 1, online softmax per unit).
+//   * two kernels share everything above and the merge tail: attn_stream_kernel (the one that runs: value steps of
+//     unit u interleaved with the score stages of unit u + 1, online softmax per unit, any split length) and
+//     attn_mfma_kernel (groups of 4 units: score pass, softmax, value pass; the fallback for T = 0 and for splits of
+//     more than 64 units per wave, and the A/B reference).
 #include <type_traits>
 
 #include "common.h"
@@ -907,14 +908,13 @@ __device__ __forceinline__ void v_step(const unsigned (&e)[8], const unsigned (&
 }
 
 // =====================================================================================================
-// Pipelined kernel.
+// Pieces of the pipelined schedule (used by the streaming kernel below).
 //
-// Why a second kernel: in the grouped kernel above a wave runs "score pass of 4 units" (LDS-bound: ~7 LDS
-// cycles per random K gather), then "value pass of 4 units" (issue-bound: v_perm address + pack work and the
-// 32x32x16 MFMAs), one after the other, and with one workgroup per CU nothing else fills the idle pipe.
-// Here both codebooks are in LDS before the loop, the softmax is online PER UNIT, and the value steps of unit
-// u are interleaved instruction by instruction with the score stages of unit u + 1, so the LDS pipe and the
-// vector/matrix issue work at the same time.  Loads: everything is requested at the top (tables first).
+// In the grouped kernel above a wave runs "score pass of 4 units" (LDS-bound: ~7 LDS cycles per random K gather), then
+// "value pass of 4 units" (issue-bound: v_perm address + pack work and the 32x32x16 MFMAs), one after the other, and
+// with one workgroup per CU nothing else fills the idle pipe.  In the pipelined schedule both codebooks are in LDS
+// before the loop, the softmax is online PER UNIT, and the value steps of unit u are interleaved instruction by
+// instruction with the score stages of unit u + 1, so the LDS pipe and the vector/matrix issue work at the same time.
 // =====================================================================================================
 // online softmax over N new scores of this lane's column (head): updates (m_run, l_run), rescales O when a
 // running maximum moves, turns the scores into probabilities in place
@@ -984,277 +984,68 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
     m_run = m_new;
 }
 
-__global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_pipe_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = blockIdx.x;
-    const int bh = blockIdx.y;
-    const int b = bh / p.nh_k, hk = bh % p.nh_k;
-    const int G = p.G;
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i dl = {p.T, p.r, p.rstart, 0};
-    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const bool dbg_on = p.dbg != nullptr;
-#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
-    stamp_lds_clear(dbg_on, lane, wave);
-    STAMP(0);
-    const int q4 = lane >> 4, c16 = lane & 15;
-
-    v8f16 qb[4];
-    {
-        const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            v4u t = *(const v4u *)(qv + 8 * s);
-            if (c16 >= G) t = v4u{0, 0, 0, 0};
-            qb[s] = __builtin_bit_cast(v8f16, t);
-        }
-    }
-    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
-    h2 new_k = {}, new_v = {};
-    if (append_wave) {
-        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
-        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
-    }
-    // ---- request order = need order, and not everything up front: the CU's load path takes ~25 cycles per
-    //      1-KiB wave request (measured: 12 more requests per wave in front of the barrier moved it by 1.7 us),
-    //      so only what the first scores need is requested before the K-codebook barrier - the first unit's
-    //      code bytes (HBM latency) ahead of the codebook (L2) - and the rest rides between compute stages. ----
-    // the first half of the K codebook goes out before the scalar round trips (lengths, page ids) that the code
-    // requests need: their latency hides behind it
-    v4u tabk[8], tabv[8];
-    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
-    {
-        const v4u *ks = (const v4u *)p.k_tab;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
-    }
-    if (p.dev_lengths)
-        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
-    int T = dl[0], r_old = dl[1], rstart = dl[2];
-    clamp_lengths(p, T, r_old, rstart);            // T <= the host bound the grid was sized for; r, start inside the window
-    const int r = r_old + (p.k_new ? 1 : 0);       // fused append: the new token is window row r_old
-    // The T tokens that are actually there (device-resident lengths: the host sized the grid for its BOUND on T) are
-    // dealt to the nsplit splits in whole 32-token units, as evenly as units allow: the first (units % nsplit) splits
-    // carry one unit more.  (Uniform split lengths rounded up to a page left the last splits short or empty and made
-    // most waves of the others run a fifth unit as soon as T passed 32 x 1024.)
-    const int units_total = (T + 31) >> 5;
-    const int units_q = units_total / p.nsplit, units_r = units_total - units_q * p.nsplit;
-    const int u_begin = split * units_q + (split < units_r ? split : units_r);
-    const int t_begin = u_begin << 5;
-    const int t_end = min((u_begin + units_q + (split < units_r ? 1 : 0)) << 5, T);
-    const int n_units = (t_end - t_begin + 31) >> 5;
-    const int n_mine = n_units > wave ? (n_units - wave + kNW - 1) / kNW : 0;
-    const int T_ld = T > 0 ? T : 1;
-    const int t_last = (T_ld - 1) & ~31;
-    // unit j of this wave starts at token t_begin + 32*(wave + j*kNW); slots past the last unit re-request the
-    // unit that holds token T-1 (L2 hits), so that no code load sits in a conditional (counted waits)
-#define UNIT_T(j) ((j) < n_mine ? t_begin + 32 * (wave + (j) * kNW) : t_last)
-    UnitCodes ring[kRing];
-    PidPair pid4[kRing];
-    {
-        int pg[kRing];
-#pragma unroll
-        for (int k = 0; k < kRing; ++k) pg[k] = UNIT_T(k) >> p.ps_shift;
-        load_pids4(p, bh, pg, pid4);
-    }
-    load_unit_k(p, b, hk, pid4[0], UNIT_T(0), T_ld, lane, ring[0]);
-    load_unit_v(p, pid4[0], UNIT_T(0), lane, ring[0]);
-    {
-        const v4u *ks = (const v4u *)p.k_tab;
-#pragma unroll
-        for (int i = 4; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
-    }
-    load_unit_k(p, b, hk, pid4[1], UNIT_T(1), T_ld, lane, ring[1]);
-    load_unit_v(p, pid4[1], UNIT_T(1), lane, ring[1]);
-
-    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
-    const bool has_res = wave < rcnt;
-    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
-    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
-    ResTile rt;
-    if (has_res) load_res_tile(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
-    STAMP(7);
-    {
-        v4u *ld = (v4u *)smem;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabk[i];
-    }
-    STAMP(8);
-    __syncthreads();
-    STAMP(1);
-
-    float m_run = -INFINITY, l_run = 0.f;
-    v16f32 O[2][2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
-    if (append_wave) {
-        int row_n = rstart + r_old;
-        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
-        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
-        *(h2 *)(p.k_res_w + o) = new_k;
-        *(h2 *)(p.v_res_w + o) = new_v;
-    }
-    // residual tile of this wave first: it needs neither codebook
-    if (has_res) {
-        float scr[4];
-        score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
-        softmax_online<4>(scr, m_run, l_run, O, G, lane);
-        value_res_tile(rt, scr, O);
-    }
-    STAMP(2);
-
-    const unsigned kbase = (unsigned)q4 * 16u * 1024u;
-    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);
-    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);
-
-    // ---- the pipeline.  Unit u lives in ring slot u & 3.  a[]: K gathers of 2 score stages in flight; e[]: V
-    //      gathers of 2 value steps.  LDS results come back in issue order: every wait is a counted lgkmcnt.
-    //      BLOCK(u): the 4 value steps of unit u interleaved with the 8 score stages of unit u + 1 (stage st's
-    //      MFMA is followed at once by the gathers of stage st + 2 into the same registers); the first gathers of
-    //      the next block go out before the softmax bubble; LOADS = the global requests that ride in this block.
-    //      (K gathers prefetched for a unit that does not exist read stale code bytes - any byte is a valid
-    //      code - and are never consumed.) ----
-    unsigned a[2][4], e[2][8], P[2][4];
-    float sc[8];
-#define KG(SL, ST) k_gather(ring[SL].k[(ST) >> 2][(ST) & 3], kbase + ((ST) & 3) * 4096, a[(ST) & 1])
-#define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
-        as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
-#define VG(SL, I) v_gather(ring[SL].v, I, vconst0, vconst1, e[(I) & 1])
-#define VS(I) v_step(e[(I) & 1], P[(I) & 1], O[(I) >> 1])
-    /* raw scores out of the accumulators; only a unit that reaches past the split's end (wave-uniform) is masked */  \
-#define SCORES_OUT(u)                                                                                              \
-    {                                                                                                              \
-        const int t_u = t_begin + 32 * (wave + (u) * kNW);                                                         \
-        if (t_u + 32 <= t_end) {                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[i] = D[i >> 2][i & 3];                                \
-        } else {                                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
-                sc[i] = t_u + 16 * (i >> 2) + 4 * q4 + (i & 3) < t_end ? D[i >> 2][i & 3] : -INFINITY;             \
-        }                                                                                                          \
-    }
-#define BLOCK(U4, u, LOADS)                                                                                        \
-    {                                                                                                              \
-        v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-            VS(i);                                                                                                 \
-            if (i < 3) VG(U4, i + 1);                                                                              \
-            KM(2 * i);                                                                                             \
-            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 2);                                                              \
-            KM(2 * i + 1);                                                                                         \
-            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 3);                                                              \
-            if (i == 0) { LOADS }                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                     \
-        }                                                                                                          \
-        VG(((U4) + 1) & 3, 0);                                                                                     \
-        KG(((U4) + 2) & 3, 0);                                                                                     \
-        KG(((U4) + 2) & 3, 1);                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        SCORES_OUT((u) + 1)                                                                                        \
-        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
-        value_prep(sc, P);                                                                                         \
-    }
-#define VALUE_ALONE(U4)                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-        if (i < 3) VG(U4, i + 1);                                                                                  \
-        VS(i);                                                                                                     \
-    }
-    {
-        // Every wave runs the 4-unit chain straight through (a unit the wave does not have re-reads the unit
-        // holding token T - 1 and is masked to -inf: the host picks this kernel only when a split holds 25..40
-        // units, so that is at most one unit per wave); a wave with a fifth unit appends one block.
-        PidPair pid5 = pid4[0];
-        if (n_mine > kRing) pid5 = load_pids(p, bh, UNIT_T(kRing) >> p.ps_shift);      // wave-uniform, rare
-        // prologue: the 8 score stages of unit 0; the V codebook and the next code bytes are requested in between
-        {
-            const v4u *vs = (const v4u *)p.v_tab_col;
-            v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            KG(0, 0);
-            KG(0, 1);
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                // the codebook requests first: its LDS store waits for everything requested before it, and
-                // must not wait for HBM-bound code bytes
-                if (st < 4) {
-                    tabv[2 * st] = vs[((2 * st + rot) & 7) * (kNW * 64) + tid];
-                    tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & 7) * (kNW * 64) + tid];
-                }
-                KM(st);
-                if (st + 2 < 8) KG(0, st + 2);
-                if (st == 4) load_unit_k(p, b, hk, pid4[2], UNIT_T(2), T_ld, lane, ring[2]);
-                if (st == 6) load_unit_v(p, pid4[2], UNIT_T(2), lane, ring[2]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            SCORES_OUT(0)
-        }
-        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);
-        value_prep(sc, P);
-        STAMP(16);
-        {
-            v4u *ldv = (v4u *)(smem + kVBase);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ldv[((i + rot) & 7) * (kNW * 64) + tid] = tabv[i];
-        }
-        STAMP(12);
-        __syncthreads();
-        STAMP(13);
-        VG(0, 0);
-        KG(1, 0);
-        KG(1, 1);
-        BLOCK(0, 0, load_unit_k(p, b, hk, pid4[3], UNIT_T(3), T_ld, lane, ring[3]);
-                    load_unit_v(p, pid4[3], UNIT_T(3), lane, ring[3]);)
-        if (n_mine > kRing) load_unit_pid(p, b, hk, pid5, UNIT_T(kRing), T_ld, lane, ring[0]);
-        STAMP(17);
-        BLOCK(1, 1, )
-        STAMP(18);
-        BLOCK(2, 2, )
-        STAMP(19);
-        if (n_mine > kRing) {
-            BLOCK(3, 3, )
-            VALUE_ALONE(0)
-        } else {
-            VALUE_ALONE(3)
-        }
-    }
-#undef KG
-#undef KM
-#undef VG
-#undef VS
-#undef SCORES_OUT
-#undef BLOCK
-#undef VALUE_ALONE
-#undef UNIT_T
-    STAMP(3);
-    merge_and_publish(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
-#undef STAMP
-}
-
 // =====================================================================================================
-// Streaming kernel: the pipelined schedule for ANY split length (M = 64).
+// Streaming kernel: the pipelined schedule for ANY split length, M = 64 and M = 32.
 //
-// What changed against attn_mfma_pipe_kernel (which it replaces on every shape it covers):
+// What changed against round 1's 4-unit pipelined kernel (which it replaced):
 //   * units are dealt to (split, wave) by PAGE, strided: page (j * ppr + wave / upp) * nsplit + split goes to round j of
 //     the wave (upp = units per page, ppr = 8 / upp pages per workgroup and round), so where a wave reads does not depend
 //     on the context length T - only HOW MANY units it has does.  The page ids of a wave's first 64 rounds are ONE
 //     vector load (lane = round) issued as the first instruction; each unit's id is then a v_readlane.  No scalar-cache
 //     round trip sits between the kernel start and the first code request, device-resident lengths included
-//     (attn_mfma_pipe_kernel: lengths -> split range -> page ids -> codes, two dependent s_load round trips);
-//   * the block "values of unit j | scores of unit j + 1" repeats for as many units as the wave has, the ring slot of
-//     unit j refilled with unit j + 4 right behind it (never in a conditional: rounds past the last unit re-read it), so a
-//     split of 8, 16 or 128 units per wave runs the same interleaved schedule (batch >= 2, 128K contexts);
+//     (round 1: lengths -> split range -> page ids -> codes, two dependent s_load round trips);
+//   * the block "values of unit j | scores of unit j + 1" repeats for as many units as the wave has: whole rounds of
+//     four units run in a loop (ring slot = unit & 3, the slot of unit j refilled with unit j + 4 right behind it, never
+//     in a conditional: rounds past the last unit re-read it), the up to three units beyond the whole rounds run one by
+//     one from the ring slots the last round refilled.  (hipcc keeps the loop at ~235 VGPRs only as long as no branch
+//     leaves it with the pipeline state live: early exits, a switch over the slot, or a remainder chain of blocks each
+//     spilled hundreds of registers; a self-contained unit behind a branch does not.)
 //   * whole pages belong to one wave pair, so rows past T - 1 of the last unit stay inside an allocated page: no row
 //     clamping on paged K.
 // MODE 0: K and V paged, int32 ids (PagedPQCache).  MODE 1: row-major K, V in dense scratch pages (the reference's
 // 10-arg layout after the transpose).  MODE 2: anything else, by run-time flags.
 // =====================================================================================================
-template <int MODE>
+template <int MS> struct StreamTypes;
+template <> struct StreamTypes<64> { typedef UnitCodes Unit; typedef unsigned E[8]; };
+template <> struct StreamTypes<32> { typedef UnitCodes32 Unit; typedef unsigned E[2][8]; };
+
+// the K gathers of score stage st (0..7) of a unit
+__device__ __forceinline__ void st_kgather(const UnitCodes &u, int st, unsigned kbase, unsigned (&a)[4]) {
+    k_gather(u.k[st >> 2][st & 3], kbase + (st & 3) * 4096, a);
+}
+__device__ __forceinline__ void st_kgather(const UnitCodes32 &u, int st, unsigned kbase, unsigned (&a)[4]) {
+    k_gather32(u.k[st >> 2][(st & 3) >> 1], st & 3, kbase + (st & 3) * 4096, a);
+}
+// the V gathers of value step i (M = 64: 4 steps of 8 four-byte gathers; M = 32: 2 steps of 8 eight-byte gathers)
+__device__ __forceinline__ void st_vgather(const UnitCodes &u, int i, unsigned vconst0, unsigned vconst1, unsigned (&e)[8]) {
+    v_gather(u.v, i, vconst0, vconst1, e);
+}
+__device__ __forceinline__ void st_vgather(const UnitCodes32 &u, int i, unsigned vconst0, unsigned, unsigned (&e)[2][8]) {
+    const unsigned w0 = u.v[0][2 * i], w1 = u.v[0][2 * i + 1];
+    const unsigned sel[4] = {0x03020400u, 0x03020500u, 0x03020600u, 0x03020700u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const v2u t = lds64(__builtin_amdgcn_perm(j < 4 ? w0 : w1, vconst0, sel[j & 3]));
+        e[0][j] = t[0];
+        e[1][j] = t[1];
+    }
+}
+// value step i: pack the gathered centroids and accumulate
+__device__ __forceinline__ void st_vstep(const unsigned (&e)[8], const unsigned (&Ps)[4], int i, v16f32 (&O)[2][2]) {
+    v_step(e, Ps, O[i >> 1]);
+}
+__device__ __forceinline__ void st_vstep(const unsigned (&e)[2][8], const unsigned (&Ps)[4], int, v16f32 (&O)[2][2]) {
+    v_step(e[0], Ps, O[0]);      // dims 4m + 0, 1
+    v_step(e[1], Ps, O[1]);      // dims 4m + 2, 3
+}
+
+template <int MS, int MODE>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) {
+    typedef typename StreamTypes<MS>::Unit Unit;
+    typedef typename StreamTypes<MS>::E EBuf;
+    constexpr int kLog2M = MS == 64 ? 6 : 5;
+    constexpr int NV = MS == 64 ? 4 : 2;       // value steps per unit (16 tokens each for M = 64 subspaces in two halves)
+    constexpr int SPV = 8 / NV;                // score stages that ride along with one value step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1281,7 +1072,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const int pg0 = wp * p.nsplit + split;
     const int pg_step = p.nsplit << (3 - ups);
     const int tin = uw << 5;
-    // page ids of rounds 0..63 (lane = round), the oldest loads of the wave
+    // page ids of rounds 0..63 (lane = round): the oldest loads of the wave
     int vpk = 0, vpv = 0;
     {
         int pgl = pg0 + lane * pg_step;
@@ -1307,12 +1098,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
         new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
     }
+    // the K codebook goes out before anything that depends on a length or a page id (the CU's load path takes ~28 cycles
+    // per 1-KiB wave request, in order: what is requested first is there first)
     v4u tabk[8], tabv[8];
     const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
     {
         const v4u *ks = (const v4u *)p.k_tab;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+        for (int i = 0; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
     }
     if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4); only the masks and the window depend on it
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
@@ -1325,10 +1118,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const int j_last = n_mine > 0 ? n_mine - 1 : 0;
     const int T_ld = T > 0 ? T : 1;
 
-    // ---- one unit's four 16-byte requests into ring slot SL; J is wave-uniform; rounds past the wave's last unit
+    // ---- residual window rows of this split, dealt to the waves round-robin (see load_res_tile) ----
+    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
+    const bool has_res = wave < rcnt;
+    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    ResTile rt;
+    if (has_res) load_res_tile<MS>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+
+    // ---- one unit's 16-byte requests into ring slot SL; J is wave-uniform; rounds past the wave's last unit
     //      re-request that unit (L2 hits, never consumed), so that no code load sits in a conditional ----
-    UnitCodes ring[kRing];
-    const unsigned k_lane_off = ((unsigned)c16 << 6) + 16u * q4;                       // row c16 (+16 for g2 = 1), quarter q4
+    Unit ring[kRing];
+    typedef typename std::conditional<MS == 64, gptr_v4u, gptr_v2u>::type KPtr;      // global address space: no FLAT loads
+    const unsigned k_lane_off = ((unsigned)c16 << kLog2M) + (unsigned)(MS / 4) * q4;    // row c16 (+16 for g2 = 1), quarter q4
     const unsigned v_lane_off = ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
 #define UNIT_REQ(SL, J)                                                                                            \
     {                                                                                                              \
@@ -1337,33 +1139,22 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         gptr_u8 kb_;                                                                                               \
         if (k_paged) {                                                                                             \
             const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
-            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << 6));                                     \
-            ring[SL].k[0] = *(gptr_v4u)(kb_ + k_lane_off);                                                         \
-            ring[SL].k[1] = *(gptr_v4u)(kb_ + k_lane_off + 1024u);                                                 \
+            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << kLog2M));                                \
+            _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
+                ring[SL].k[g2] = *(KPtr)(kb_ + k_lane_off + ((16u * g2) << kLog2M));                               \
         } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
             const int tu_ = t0 + jc_ * t_step;                                                                     \
             kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
-            ring[SL].k[0] = *(gptr_v4u)(kb_ + (((unsigned)min(tu_ + c16, T_ld - 1) << 6) + 16u * q4));             \
-            ring[SL].k[1] = *(gptr_v4u)(kb_ + (((unsigned)min(tu_ + c16 + 16, T_ld - 1) << 6) + 16u * q4));        \
+            _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
+                ring[SL].k[g2] = *(KPtr)(kb_ + (((unsigned)min(tu_ + c16 + 16 * g2, T_ld - 1) << kLog2M) +         \
+                                                (unsigned)(MS / 4) * q4));                                         \
         }                                                                                                          \
-        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (6 + p.ps_shift)) + tin);                              \
+        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + p.ps_shift)) + tin);                         \
         ring[SL].v[0] = *(gptr_v4u)(vb_ + v_lane_off);                                                             \
-        ring[SL].v[1] = *(gptr_v4u)(vb_ + v_lane_off + (32u << p.ps_shift));                                       \
+        if (MS == 64) ring[SL].v[MS == 64 ? 1 : 0] = *(gptr_v4u)(vb_ + v_lane_off + (32u << p.ps_shift));          \
     }
     UNIT_REQ(0, 0)
-    {
-        const v4u *ks = (const v4u *)p.k_tab;
-#pragma unroll
-        for (int i = 4; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
-    }
     UNIT_REQ(1, 1)
-
-    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
-    const bool has_res = wave < rcnt;
-    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
-    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
-    ResTile rt;
-    if (has_res) load_res_tile(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
     STAMP(7);
     {
         v4u *ld = (v4u *)smem;
@@ -1398,16 +1189,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     STAMP(2);
 
     const unsigned kbase = (unsigned)q4 * 16u * 1024u;
-    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << 2);
-    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);
+    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3));
+    const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);      // M = 64 only
 
-    unsigned a[2][4], e[2][8], P[2][4];
+    unsigned a[2][4], P[2][4];
+    EBuf e[2];
     float sc[8];
-#define KG(SL, ST) k_gather(ring[SL].k[(ST) >> 2][(ST) & 3], kbase + ((ST) & 3) * 4096, a[(ST) & 1])
+#define KG(SL, ST) st_kgather(ring[SL], ST, kbase, a[(ST) & 1])
 #define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
         as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
-#define VG(SL, I) v_gather(ring[SL].v, I, vconst0, vconst1, e[(I) & 1])
-#define VS(I) v_step(e[(I) & 1], P[(I) & 1], O[(I) >> 1])
+#define VG(SL, I) st_vgather(ring[SL], I, vconst0, vconst1, e[(I) & 1])
+#define VS(I) st_vstep(e[(I) & 1], P[MS == 64 ? ((I) & 1) : (I)], I, O)
     // raw scores of round J out of the accumulators; only the unit that holds token T - 1 (wave-uniform) is masked; a
     // round whose first token is past T - 1 (only the prologue of a wave without whole rounds meets one) gives -inf
 #define SCORES_OUT(J)                                                                                              \
@@ -1420,19 +1212,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 sc[i] = t_u + 16 * (i >> 2) + 4 * q4 + (i & 3) < T ? D[i >> 2][i & 3] : -INFINITY;                 \
         }                                                                                                          \
     }
-    // BLOCK: the 4 value steps of the unit in slot U4 (round J) interleaved with the 8 score stages of the unit in slot
-    // U4 + 1 (round J + 1); then the first gathers of the next block, the online softmax of round J + 1 and the refill
-    // of slot U4 with round J + 4.
+    // BLOCK: the value steps of the unit in slot U4 (round J) interleaved with the 8 score stages of the unit in slot
+    // U4 + 1 (round J + 1); then the first gathers of the next block, the refill of slot U4 with round J + 4 and the
+    // online softmax of round J + 1.
 #define BLOCK(U4, J)                                                                                               \
     {                                                                                                              \
         v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                           \
             VS(i);                                                                                                 \
-            if (i < 3) VG(U4, i + 1);                                                                              \
-            KM(2 * i);                                                                                             \
-            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 2);                                                              \
-            KM(2 * i + 1);                                                                                         \
-            if (i < 3) KG(((U4) + 1) & 3, 2 * i + 3);                                                              \
+            if (i + 1 < NV) VG(U4, i + 1);                                                                         \
+            _Pragma("unroll") for (int k = 0; k < SPV; ++k) {                                                      \
+                KM(SPV * i + k);                                                                                   \
+                if (SPV * i + k + 2 < 8) KG(((U4) + 1) & 3, SPV * i + k + 2);                                      \
+            }                                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                          \
         VG(((U4) + 1) & 3, 0);                                                                                     \
@@ -1445,8 +1237,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         value_prep(sc, P);                                                                                         \
     }
 #define VALUE_ALONE(U4)                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-        if (i < 3) VG(U4, i + 1);                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                               \
+        if (i + 1 < NV) VG(U4, i + 1);                                                                             \
         VS(i);                                                                                                     \
     }
     // One unit on its own (the up to three units a wave has beyond its whole rounds of four): scores, softmax, values,
@@ -1477,6 +1269,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             KG(0, 1);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
+                // the codebook requests first: its LDS store waits for everything requested before it, and
+                // must not wait for HBM-bound code bytes
                 if (st < 4) {
                     tabv[2 * st] = vs[((2 * st + rot) & 7) * (kNW * 64) + tid];
                     tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & 7) * (kNW * 64) + tid];
@@ -1541,7 +1335,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef VALUE_ALONE
 #undef UNIT_REQ
     STAMP(3);
-    merge_and_publish(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
+    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
 #undef STAMP
 }
 
@@ -1566,8 +1360,7 @@ bool attn_mfma_supported(const AttnParams &p) {
     return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
 }
 
-// A/B knob (million_set_force_generic 2 / 3): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only,
-// 2 = the round-1 choice (pipelined 4-unit kernel for splits of 25..40 units, grouped kernel otherwise)
+// A/B knob (million_set_force_generic 2): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only
 static int g_mfma_policy = 0;
 void set_mfma_policy(int policy) { g_mfma_policy = policy; }
 
@@ -1593,26 +1386,31 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_mfma_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     // streaming kernel: rounds per wave = ceil(T / (ns * 256 tokens)) must fit the 64 page ids a wave preloads
-    const bool stream_ok = p.M == 64 && p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64;
-    if (p.M == 32) {
+    const bool stream_ok = p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64;
+    const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
+    const dim3 grid(ns, bh), block(kNW * 64);
+    if (g_mfma_policy == 0 && stream_ok) {
+        if (p.M == 64) {
+            if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<64, 0>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<64, 1>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_stream_kernel<64, 2>), grid, block, kLdsBytes, s, p);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<32, 0>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<32, 1>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_stream_kernel<32, 2>), grid, block, kLdsBytes, s, p);
+        }
+    } else if (p.M == 32) {
         if (p.T > 0) hipLaunchKernelGGL((attn_mfma_kernel<true, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_mfma_kernel<false, 32>), dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
-    } else if (g_mfma_policy == 0 && stream_ok) {
-        if (p.k_paged && !p.v_identity && !p.ids64)
-            hipLaunchKernelGGL(attn_stream_kernel<0>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
-        else if (!p.k_paged && p.v_identity)
-            hipLaunchKernelGGL(attn_stream_kernel<1>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
-        else
-            hipLaunchKernelGGL(attn_stream_kernel<2>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
-    } else if (g_mfma_policy == 2 && p.T > 0 && len > 24 * 32 && len <= 40 * 32)
-        hipLaunchKernelGGL(attn_mfma_pipe_kernel, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
-    else if (p.T > 0)
+    } else if (p.T > 0)
         hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);
     else
         hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(ns, bh), dim3(kNW * 64), kLdsBytes, s, p);

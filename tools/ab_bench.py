@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Development helper: time the fused decode-attention launch of ONE library build at several shapes (back-to-back
+launch period over rotating layers, HIP events) and compare its output with the grouped kernel's.
+    MILLION_HIP_LIB=build/ab/libmillion_exp1.so python tools/ab_bench.py [--cfg bs,T,M ...]"""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from million_amd import _lib as L, ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", nargs="*", default=["1,32768,64", "2,32768,64", "4,32768,64", "1,131072,64", "1,131072,32", "1,32832,64"])
+ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--shuffle-pages", action="store_true", help="random page permutation (default: ids in allocation order, as PagedPQCache hands them out)")
+ap.add_argument("--iters", type=int, default=96)
+ap.add_argument("--dev-lengths", action="store_true")
+ap.add_argument("--zero-codes", action="store_true", help="diagnostic: all code bytes 0 (every LDS gather is a broadcast: no bank conflicts)")
+ap.add_argument("--same-page", action="store_true", help="diagnostic: every page id = 0 (codes come from L2, not HBM)")
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+lib = L.load()
+tag = os.environ.get("MILLION_HIP_LIB", "in-tree")
+for cfg in args.cfg:
+    bs, T, M = (int(x) for x in cfg.split(","))
+    nh, nhk, d, C, ps, r = 32, 8, 128, 256, 64, 100
+    n_pages = (T + ps - 1) // ps
+    states = []
+    nl = max(4, min(args.layers, int(6e9 // (2 * bs * nhk * n_pages * ps * M))))      # keep the pools under ~6 GB
+    for l in range(nl):
+        kpool = torch.randint(0, 256, (bs * nhk * n_pages, ps, M), dtype=torch.uint8, device=dev)
+        vpool = torch.randint(0, 256, (bs * nhk * n_pages, M, ps), dtype=torch.uint8, device=dev)
+        ids = (torch.randperm(bs * nhk * n_pages, device=dev) if args.shuffle_pages else torch.arange(bs * nhk * n_pages, device=dev)).to(torch.int32).reshape(bs, nhk, n_pages)
+        if args.zero_codes:
+            kpool.zero_(); vpool.zero_()
+        if args.same_page:
+            ids.zero_()
+        states.append((kpool, vpool, ids))
+    kc = ops.prepare_cents(torch.randn(M, C, d // M, device=dev).half(), cache=False)
+    vc = ops.prepare_cents(torch.randn(M, C, d // M, device=dev).half(), cache=False)
+    q = torch.randn(bs, nh, 1, d, device=dev).half()
+    kr = torch.randn(bs, nhk, 128, d, device=dev).half()
+    vr = torch.randn(bs, nhk, 128, d, device=dev).half()
+    dl = torch.tensor([[T, r, 0, 0]] * bs, dtype=torch.int32, device=dev) if args.dev_lengths else None
+
+    def run(l):
+        kp, vp, ids = states[l % len(states)]
+        return ops.pq_decode_attn(q, kp, vp, kc, vc, kr, vr, r, M=M, C=C, n_tokens=T, k_page_ids=ids, v_page_ids=ids,
+                                  page_size=ps, dev_lengths=dl)
+
+    lib.million_set_force_generic(2)        # grouped kernel as the cross-check
+    ref = run(0).float()
+    lib.million_set_force_generic(0)
+    out = run(0).float()
+    err = ((out - ref).norm() / ref.norm()).item()
+    for i in range(16):
+        run(i)
+    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(5e7))
+        e0.record()
+        for i in range(args.iters):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / args.iters)
+    alg = 2 * bs * nhk * T * M + 2 * bs * nhk * r * d * 2 + 2 * M * C * (d // M) * 2 + bs * nh * d * 4
+    print(f"{tag:34s} bs={bs} T={T:6d} M={M}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs grouped {err:.1e}", flush=True)
+    del states
+    torch.cuda.empty_cache()

@@ -19,7 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = ROOT / "gpurun_out"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
-KERNEL = "attn_mfma"        # the fused decode-attention launch: attn_mfma_pipe_kernel (headline shape) / attn_mfma_kernel
+KERNEL = "attn_"            # the fused decode-attention launch: attn_stream_kernel (attn_mfma_kernel: fallback)
 
 summary = {"kernel": KERNEL, "tag": tag}
 ks = glob.glob(str(src / "prof_kt" / "*" / "*_kernel_stats.csv"))

@@ -20,10 +20,13 @@ ap.add_argument("--bs", type=int, default=1)
 ap.add_argument("--r", type=int, default=100)
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--grouped", action="store_true", help="labels of the grouped kernel")
+ap.add_argument("--raw", action="store_true", help="print every stamp id that was written, ordered by mean time")
+ap.add_argument("--M", type=int, default=64)
+ap.add_argument("--dev-lengths", action="store_true")
 ap.add_argument("--policy", type=int, default=0, help="million_set_force_generic value (2 = grouped only, 3 = prefer pipelined)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
-M, C, d, ps = 64, 256, 128, 64
+M, C, d, ps = args.M, 256, 128, 64
 bs, nh, nhk, T = args.bs, args.nh, args.nhk, args.T
 n_pages = (T + ps - 1) // ps
 lib = L.load()
@@ -34,11 +37,12 @@ for l in range(args.layers):
     vpool = torch.randint(0, 256, (bs * nhk * n_pages, M, ps), dtype=torch.uint8, device=dev)
     ids = torch.randperm(bs * nhk * n_pages, device=dev).to(torch.int32).reshape(bs, nhk, n_pages)
     states.append((kpool, vpool, ids))
-kc = ops.prepare_cents(torch.randn(M, C, 2, device=dev).half())
-vc = ops.prepare_cents(torch.randn(M, C, 2, device=dev).half())
+kc = ops.prepare_cents(torch.randn(M, C, d // M, device=dev).half())
+vc = ops.prepare_cents(torch.randn(M, C, d // M, device=dev).half())
 q = torch.randn(bs, nh, 1, d, device=dev).half()
 kr = torch.randn(bs, nhk, 128, d, device=dev).half()
 vr = torch.randn(bs, nhk, 128, d, device=dev).half()
+dlen = torch.tensor([[T, args.r, 0, 0]] * bs, dtype=torch.int32, device=dev) if args.dev_lengths else None
 NW, NS = 8, 32                               # common.h: kStampWaves, kStampSlots
 stamps = torch.zeros(bs * nhk * 64 * NW * NS, dtype=torch.int64, device=dev)
 
@@ -46,7 +50,7 @@ stamps = torch.zeros(bs * nhk * 64 * NW * NS, dtype=torch.int64, device=dev)
 def run(l):
     kp, vp, ids = states[l % args.layers]
     return ops.pq_decode_attn(q, kp, vp, kc, vc, kr, vr, args.r, M=M, C=C, n_tokens=T, k_page_ids=ids, v_page_ids=ids,
-                              page_size=ps)
+                              page_size=ps, dev_lengths=dlen)
 
 
 for i in range(2 * args.layers):
@@ -72,13 +76,13 @@ if args.grouped:     # labels of the grouped kernel (attn_mfma_kernel)
              (24, "residual tile scores, softmax update"), (12, "append store, V codebook -> LDS"),
              (13, "barrier 2"), (3, "residual tile values, value pass (+ later groups)"),
              (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
-else:                # labels of the pipelined kernel (attn_mfma_pipe_kernel)
-    order = [(0, "kernel start"), (7, "requested: q, unit 0 bytes, K codebook, K bytes unit 1, residual tile"),
+else:                # labels of the streaming kernel (attn_stream_kernel)
+    order = [(0, "kernel start"), (7, "requested: page ids, q, K codebook, residual tile, units 0-1"),
              (8, "K codebook written to LDS"), (1, "barrier 1 (K codebook)"), (2, "residual tile done"),
              (16, "prologue: scores of unit 0 (+ V codebook / unit 1-2 requests), softmax"),
-             (12, "V codebook written to LDS"), (13, "barrier 2 (V codebook)"), (17, "block 0: values 0 | scores 1"),
-             (18, "block 1: values 1 | scores 2"), (19, "block 2: values 2 | scores 3"),
-             (3, "values of the last unit (+ block 3 where a fifth unit exists)"),
+             (12, "V codebook written to LDS"), (13, "barrier 2 (V codebook)"), (17, "first whole round of 4 blocks (splits of >= 8 units per wave)"),
+             (19, "blocks of the last whole round"),
+             (3, "values of the last unit of the round (+ single units beyond the whole rounds)"),
              (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
 s = last
 t0 = s[:, :, 0].min()
@@ -94,6 +98,17 @@ for name, sel in (("waves 0-3 (carry a residual tile at r=100, 32 splits)", s[:,
         d = (sel[:, sid] - sel[:, prev]) / 100.0
         print(f"  @{at.mean():6.2f}  +{d.mean():5.2f} (min {d.min():5.2f} max {d.max():5.2f})  {label}")
         prev = sid
+if args.raw:
+    for name, sel in (("waves 0-3", s[:, :4, :].reshape(-1, NS)), ("waves 4-7", s[:, 4:, :].reshape(-1, NS))):
+        rows = []
+        for sid in range(1, NS):
+            ok = sel[:, sid] != 0
+            if ok.any():
+                at = (sel[ok, sid] - sel[ok, 0]) / 100.0
+                rows.append((at.mean(), sid, at.min(), at.max(), int(ok.sum())))
+        print(f"--- raw stamps, {name}: id @mean (min..max) [waves]")
+        for m_, sid, lo, hi, n in sorted(rows):
+            print(f"   stamp {sid:2d} @{m_:6.2f} ({lo:5.2f}..{hi:5.2f}) [{n}]")
 la = s[:, 0, :][s[:, 0, 11] != 0]
 if la.shape[0]:
     print("  last arrivers (%d): ticket -> weights ready %.2f | -> out written %.2f us" % (
