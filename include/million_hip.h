@@ -93,6 +93,23 @@ typedef struct {
 
 int million_pq_encode(const million_encode_desc *desc, const void *x, const void *cents /* (M,C,d_m) fp16 */,
                       void *dst, const int32_t *page_ids, million_stream_t stream);
+/* Code width: C <= 256 -> dst holds uint8 codes; 256 < C <= 65536 (nbits 9..16) -> uint16 codes in the same three
+ * layouts (reference nbits2dtype, scripts/utils/pq_utils.py:542-552; sa_encode_4d*(target_dtype=...), :449/:499).
+ * dst_stride_b / dst_stride_h stay in BYTES.  The decode-attention kernels are uint8-only, as the reference's are
+ * (setup.py:10-11); wide codes serve the dequantise-then-attend path (DynamicPQCache.update, pq_utils.py:166-220). */
+
+/* One launch per window flush.
+ * Replaces: PagedPQCache.flush_to_pages (scripts/utils/paged_pq_utils.py:130-210): encode of the oldest `desc->n` K
+ * rows and V rows of the residual window (two sa_encode_4d_keops calls, :161,:167), the permute + torch.cat that store
+ * them (:162,:173-175) and the window shift (:188-204; here: the ring start advances).
+ * desc describes the K side: X = k_rows (the K window buffer; the V window must have the same shape and strides),
+ * dst_layout = MILLION_CODES_KPAGES into k_pool; the V side is written as MILLION_CODES_VPAGES into v_pool through the
+ * same page ids.  dev_lengths (must equal desc->dev_lengths; may be NULL): the destination token and the ring start are
+ * read on the device and, once every workgroup has read them, advanced there (n_tokens += n, r -= n, resid_start =
+ * (resid_start + n) % resid_cap; the 4th word of each row is the workgroups' ticket and is left at 0).  uint8 codes. */
+int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const void *v_rows,
+                     const void *k_cents, const void *v_cents, void *k_pool, void *v_pool,
+                     const int32_t *page_ids, int32_t *dev_lengths, int resid_cap, million_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PQ decode (reconstruction).
@@ -100,8 +117,8 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
  * codes: (n_rows, M) u8 contiguous (any leading dims flattened); cents: the RAW (M, C, d_m) fp16 codebook;
  * out: (n_rows, d) fp16 contiguous.  Exact (a gather).  Used by the reference only in fallbacks and the
  * perplexity path (pq_utils.py:198-204), so this is a plain bandwidth kernel with the codebook staged in LDS. */
-int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n_rows, int d, int M, int C,
-                      million_stream_t stream);
+int million_pq_decode(const void *codes /* uint8 for C <= 256, uint16 above */, const void *cents, void *out,
+                      int64_t n_rows, int d, int M, int C, million_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused decode-step attention.
@@ -137,7 +154,9 @@ typedef struct {
     int32_t page_size;            /* PAGED: tokens per page (32, 64 or 128) */
     int32_t n_pages_cap;          /* PAGED: row length of the page-id arrays */
     int32_t page_ids_i64;         /* PAGED: 0 = page ids are int32, 1 = int64 (reference passes int64, paged_pq_utils.py:440) */
-    int32_t reserved0;
+    int32_t v_pages_dense;        /* v_layout PAGED only: 1 = the V pool passed to the call is the dense run of transposed
+                                     64-token pages million_transpose_v_codes writes (page p of (b, hk) is pool page
+                                     (b*nh_k + hk) * n_pages_cap + p): no V page-id array is read (v_page_ids may be NULL) */
     int64_t k_stride_b, k_stride_h;   /* ROWMAJOR: bytes between batches / kv heads of k_codes */
     int64_t v_stride_b, v_stride_h;   /* ROWMAJOR: same for v_codes */
     const int32_t *dev_lengths;   /* optional device array (bs, 4) = {n_tokens, r, resid_start, 0}: when set,
@@ -175,12 +194,20 @@ int million_pq_decode_attn_append(const million_attn_desc *desc, const void *q, 
                                   const void *v_cents_prepared, void *k_resid, void *v_resid, void *out,
                                   void *workspace, size_t workspace_bytes, million_stream_t stream);
 
+/* Row-major V codes (bs, nh_k, T, M) u8 (the reference's 10-argument layout, Interface.template.cu:30) -> the dense run
+ * of transposed 64-token pages ((bs*nh_k) * ceil(T/64), M, 64) that the fast kernels read with v_pages_dense = 1,
+ * page_size = 64, n_pages_cap = ceil(T/64).  Replaces the per-call pad + view + transpose + contiguous of
+ * PagedPQCache._call_paged_kernel (scripts/utils/paged_pq_utils.py:464-500).  A caller that passes the same V code
+ * tensor on many decode steps (the reference does, between two flushes) transposes once and reuses the pages;
+ * million_pq_decode_attn with v_layout = ROWMAJOR does the same transpose into its workspace on EVERY call. */
+int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh_k, int n_tokens, int M,
+                              int64_t v_stride_b, int64_t v_stride_h, million_stream_t stream);
+
 /* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = MFMA fast path, 2 = MFMA fast path
  * after transposing row-major V codes into workspace scratch (one extra launch), 0 = generic. */
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Kernel choice for A/B measurements and tests: 0 = auto (default), 1 = generic kernel only, 2 = MFMA grouped kernel
- * only (never the pipelined one), 3 = prefer the pipelined MFMA kernel (twice the splits when that brings a split into
- * its range). */
+ * only (never the streaming one). */
 void million_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------

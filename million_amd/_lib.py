@@ -33,7 +33,7 @@ class AttnDesc(ctypes.Structure):
                 ("n_tokens", c_i32), ("r", c_i32), ("resid_start", c_i32), ("resid_cap", c_i32),
                 ("resid_stride_b", c_i64), ("resid_stride_h", c_i64),
                 ("k_layout", c_i32), ("v_layout", c_i32), ("page_size", c_i32), ("n_pages_cap", c_i32),
-                ("page_ids_i64", c_i32), ("reserved0", c_i32),
+                ("page_ids_i64", c_i32), ("v_pages_dense", c_i32),
                 ("k_stride_b", c_i64), ("k_stride_h", c_i64), ("v_stride_b", c_i64), ("v_stride_h", c_i64),
                 ("dev_lengths", c_vp)]
 
@@ -46,6 +46,8 @@ SYMBOLS = {
     "million_prepare_cents": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "million_pq_encode": (c_i32, [ctypes.POINTER(EncodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "million_pq_decode": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "million_pq_flush": (c_i32, [ctypes.POINTER(EncodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "million_transpose_v_codes": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "million_attn_workspace_bytes": (c_sz, [ctypes.POINTER(AttnDesc)]),
     "million_workspace_init": (c_i32, [c_vp, c_sz, c_vp]),
     "million_pq_decode_attn": (c_i32, [ctypes.POINTER(AttnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -316,7 +316,8 @@ struct EncParams {
 int launch_attn_generic(const AttnParams &p, hipStream_t s);
 int launch_attn_mfma(const AttnParams &p, hipStream_t s);
 int launch_encode(const EncParams &p, hipStream_t s);
-int launch_decode(const uint8_t *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s);
+int launch_decode(const void *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s);
+int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, hipStream_t s);
 bool attn_mfma_shape_ok(const AttnParams &p);
 int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hipStream_t s);
 bool attn_mfma_supported(const AttnParams &p);

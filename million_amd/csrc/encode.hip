@@ -31,8 +31,10 @@ constexpr int kEncSub = 4;      // subspaces per wave
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int DM, bool F32TAB>
+// CodeT = uint8_t (C <= 256) or uint16_t (nbits 9..16: reference nbits2dtype, pq_utils.py:542-552).
+template <int DM, bool F32TAB, typename CodeT>
 __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
+    constexpr int kCB = sizeof(CodeT) * 8;      // bits per stored code
     const int lane = threadIdx.x & 63;
     const int mg = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (kEncBlock / 64) + (threadIdx.x >> 6)));
     const int m0 = mg * kEncSub;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
 #pragma unroll
         for (int k = 0; k < DM; ++k) x[j][k] = j < nsub ? (float)xp[j * DM + k] : 0.f;
 
-    unsigned codes = 0;
+    unsigned long long codes = 0;
 #pragma unroll
     for (int j = 0; j < kEncSub; ++j) {
         if (j >= nsub) break;
@@ -91,31 +93,33 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
             best_c = !(acc < best) ? best_c : c;
             best = fminf(best, acc);
         }
-        codes |= (unsigned)best_c << (8 * j);
+        codes |= (unsigned long long)(unsigned)best_c << (kCB * j);
     }
     if (!valid) return;
     const int tok = tok0 + t;
+    CodeT *dst = (CodeT *)p.dst;      // strides dsb / dsh are in bytes
     if (p.layout == MILLION_CODES_VPAGES) {
         const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
         const int off = tok % p.page_size;
 #pragma unroll
         for (int j = 0; j < kEncSub; ++j)
-            if (j < nsub) p.dst[(pid * p.M + m0 + j) * p.page_size + off] = (uint8_t)(codes >> (8 * j));
+            if (j < nsub) dst[(pid * p.M + m0 + j) * p.page_size + off] = (CodeT)(codes >> (kCB * j));
         return;
     }
-    uint8_t *row;
+    CodeT *row;
     if (p.layout == MILLION_CODES_ROWMAJOR) {
-        row = p.dst + b * p.dsb + hk * p.dsh + (long long)tok * p.M + m0;
+        row = (CodeT *)(p.dst + b * p.dsb + hk * p.dsh) + (long long)tok * p.M + m0;
     } else {
         const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
-        row = p.dst + (pid * p.page_size + tok % p.page_size) * p.M + m0;
+        row = dst + (pid * p.page_size + tok % p.page_size) * p.M + m0;
     }
-    if (nsub == kEncSub && ((size_t)row & 3) == 0) {
-        *(unsigned *)row = codes;
+    if (nsub == kEncSub && ((size_t)row & (4 * sizeof(CodeT) - 1)) == 0) {
+        if (sizeof(CodeT) == 1) *(unsigned *)row = (unsigned)codes;
+        else *(unsigned long long *)row = codes;
     } else {
 #pragma unroll
         for (int j = 0; j < kEncSub; ++j)
-            if (j < nsub) row[j] = (uint8_t)(codes >> (8 * j));
+            if (j < nsub) row[j] = (CodeT)(codes >> (kCB * j));
     }
 }
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
 // puts the centroid row into LDS with ONE vector round trip (converted to fp32 on the way) and reads it back with
 // wave-uniform (broadcast) ds_reads that pipeline; one subspace per workgroup, a quarter of the centroids per wave.
 template <int DM>
-__global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p) {
+__device__ __forceinline__ void encode_small_body(const EncParams &p, int m, int bh, int tblock) {
     // one subspace and 64 tokens per WORKGROUP: its four waves scan a quarter of the centroids each (a 4x shorter
     // dependent chain), wave 0 picks among the four candidates in centroid order (strict '<': lowest index on ties)
     constexpr int kW = kEncBlock / 64;
@@ -133,10 +137,8 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p)
     __shared__ int cand_c[kW][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int m = blockIdx.y;
-    const int bh = blockIdx.z;
     const int b = bh / p.nh_k, hk = bh % p.nh_k;
-    const int t = blockIdx.x * 64 + lane;
+    const int t = tblock * 64 + lane;
     const int cq = (p.C + kW - 1) / kW;                   // centroids per wave
     const int c0 = w * cq, c1 = min(c0 + cq, p.C);
     const f16 *cm = p.cents + (long long)m * p.C * DM;
@@ -185,8 +187,70 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p)
     }
 }
 
+// Small calls (a flush of 64 window rows: 512 (row, subspace) pairs per kv head) cannot hide the scalar-cache
+// round trips of the kernel above behind other waves: 32 dependent s_load batches of ~0.6 us each.  This variant
+// puts the centroid row into LDS with ONE vector round trip (converted to fp32 on the way) and reads it back with
+// wave-uniform (broadcast) ds_reads that pipeline; one subspace per workgroup, a quarter of the centroids per wave.
+template <int DM>
+__global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p) {
+    encode_small_body<DM>(p, blockIdx.y, blockIdx.z, blockIdx.x);
+}
+
+// ---- one launch per flush (reference flush_to_pages, paged_pq_utils.py:130-210: encode the oldest page of K rows, of
+// V rows, then move the window): blockIdx.y < M encodes K subspace y, otherwise V subspace y - M; the workgroup that
+// finishes last (ticket in the spare 4th word of the batch item's device lengths, reset by that workgroup) advances the
+// lengths - every workgroup has read them by then.  Replaces 3 launches per layer (2 x encode + lengths_advance).
+struct FlushParams {
+    EncParams k, v;
+    int *dev_lengths_w;      // writable alias of k.dev_lengths (null: host lengths, nothing to advance)
+    int n_flush, rcap;
+};
+
+template <int DM>
+__global__ __launch_bounds__(kEncBlock) void pq_flush_kernel(FlushParams f) {
+    const int M = f.k.M;
+    const bool vside = (int)blockIdx.y >= M;                    // workgroup-uniform
+    const int bh = blockIdx.z;
+    encode_small_body<DM>(vside ? f.v : f.k, vside ? blockIdx.y - M : blockIdx.y, bh, blockIdx.x);
+    if (!f.dev_lengths_w) return;
+    __syncthreads();      // every wave of this workgroup has read the lengths and issued its stores
+    if (threadIdx.x == 0) {
+        const int b = bh / f.k.nh_k;
+        int *dl = f.dev_lengths_w + b * 4;
+        const int total = (int)(gridDim.x * gridDim.y) * f.k.nh_k;      // workgroups that read batch item b's lengths
+        const int t = __hip_atomic_fetch_add(dl + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == total - 1) {
+            dl[0] += f.n_flush;
+            dl[1] -= f.n_flush;
+            dl[2] = (dl[2] + f.n_flush) % f.rcap;
+            __hip_atomic_store(dl + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, hipStream_t s) {
+    if (k.n <= 0 || k.bs * k.nh_k <= 0) return MILLION_OK;
+    FlushParams f;
+    f.k = k; f.v = v; f.dev_lengths_w = dev_lengths_w; f.n_flush = k.n; f.rcap = rcap;
+    const dim3 grid((k.n + 63) / 64, 2 * k.M, k.bs * k.nh_k);
+    switch (k.dm) {
+        case 1: hipLaunchKernelGGL((pq_flush_kernel<1>), grid, dim3(kEncBlock), 0, s, f); break;
+        case 2: hipLaunchKernelGGL((pq_flush_kernel<2>), grid, dim3(kEncBlock), 0, s, f); break;
+        case 4: hipLaunchKernelGGL((pq_flush_kernel<4>), grid, dim3(kEncBlock), 0, s, f); break;
+        case 8: hipLaunchKernelGGL((pq_flush_kernel<8>), grid, dim3(kEncBlock), 0, s, f); break;
+        default: set_error("flush: d/M=%d unsupported (1,2,4,8)", k.dm); return MILLION_ERR_SHAPE;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("flush launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
 template <int DM>
 static void launch_dm(const EncParams &p, dim3 grid, hipStream_t s) {
+    if (p.C > 256) {      // uint16 codes: the raw fp16 codebook through the scalar cache (any C)
+        hipLaunchKernelGGL((pq_encode_kernel<DM, false, uint16_t>), grid, dim3(kEncBlock), 0, s, p);
+        return;
+    }
     // fewer than ~one wave per SIMD with 4 subspaces per wave: latency-bound, take the LDS variant
     const long long waves4 = (long long)grid.x * grid.y * (kEncBlock / 64) * grid.z;
     if (waves4 < 1024) {
@@ -194,8 +258,8 @@ static void launch_dm(const EncParams &p, dim3 grid, hipStream_t s) {
         hipLaunchKernelGGL((pq_encode_small_kernel<DM>), g1, dim3(kEncBlock), 0, s, p);
         return;
     }
-    if (p.cents32) hipLaunchKernelGGL((pq_encode_kernel<DM, true>), grid, dim3(kEncBlock), 0, s, p);
-    else hipLaunchKernelGGL((pq_encode_kernel<DM, false>), grid, dim3(kEncBlock), 0, s, p);
+    if (p.cents32) hipLaunchKernelGGL((pq_encode_kernel<DM, true, uint8_t>), grid, dim3(kEncBlock), 0, s, p);
+    else hipLaunchKernelGGL((pq_encode_kernel<DM, false, uint8_t>), grid, dim3(kEncBlock), 0, s, p);
 }
 
 int launch_encode(const EncParams &p, hipStream_t s) {
@@ -234,17 +298,43 @@ __global__ __launch_bounds__(256) void pq_decode_kernel(const uint8_t *__restric
     }
 }
 
-int launch_decode(const uint8_t *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s) {
+// Codebooks that do not fit the 64 KiB LDS stage, and uint16 codes (C > 256): the same gather straight from the global
+// codebook (L2 / L1 resident).
+template <int DM, typename CodeT>
+__global__ __launch_bounds__(256) void pq_decode_global_kernel(const CodeT *__restrict__ codes, const f16 *__restrict__ cents,
+                                                               f16 *__restrict__ out, long long n_rows, int M, int C) {
+    typedef struct { f16 v[DM]; } __attribute__((aligned(2 * DM))) Entry;
+    const Entry *tab = (const Entry *)cents;
+    const long long total = n_rows * M;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx % M);
+        const unsigned c = codes[idx];
+        ((Entry *)out)[idx] = tab[(long long)m * C + (c < (unsigned)C ? c : 0u)];
+    }
+}
+
+template <int DM>
+static void launch_decode_dm(const void *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, unsigned blocks,
+                             hipStream_t s) {
+    const size_t lds = (size_t)M * C * DM * sizeof(f16);
+    if (C > 256)
+        hipLaunchKernelGGL((pq_decode_global_kernel<DM, uint16_t>), dim3(blocks), dim3(256), 0, s, (const uint16_t *)codes, cents, out, n_rows, M, C);
+    else if (lds > 64 * 1024)
+        hipLaunchKernelGGL((pq_decode_global_kernel<DM, uint8_t>), dim3(blocks), dim3(256), 0, s, (const uint8_t *)codes, cents, out, n_rows, M, C);
+    else
+        hipLaunchKernelGGL(pq_decode_kernel<DM>, dim3(blocks), dim3(256), lds, s, (const uint8_t *)codes, cents, out, n_rows, M, C);
+}
+
+// codes: uint8 for C <= 256, uint16 above (reference nbits2dtype, pq_utils.py:542-552)
+int launch_decode(const void *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s) {
     if (n_rows <= 0) return MILLION_OK;
-    const size_t lds = (size_t)M * C * dm * sizeof(f16);
-    if (lds > 64 * 1024) { set_error("decode: codebook of %zu bytes does not fit the 64 KiB LDS stage", lds); return MILLION_ERR_SHAPE; }
     long long blocks = (n_rows * M + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     switch (dm) {
-        case 1: hipLaunchKernelGGL(pq_decode_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
-        case 2: hipLaunchKernelGGL(pq_decode_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
-        case 4: hipLaunchKernelGGL(pq_decode_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
-        case 8: hipLaunchKernelGGL(pq_decode_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, codes, cents, out, n_rows, M, C); break;
+        case 1: launch_decode_dm<1>(codes, cents, out, n_rows, M, C, (unsigned)blocks, s); break;
+        case 2: launch_decode_dm<2>(codes, cents, out, n_rows, M, C, (unsigned)blocks, s); break;
+        case 4: launch_decode_dm<4>(codes, cents, out, n_rows, M, C, (unsigned)blocks, s); break;
+        case 8: launch_decode_dm<8>(codes, cents, out, n_rows, M, C, (unsigned)blocks, s); break;
         default: set_error("decode: d/M=%d unsupported (1,2,4,8)", dm); return MILLION_ERR_SHAPE;
     }
     const hipError_t e = hipGetLastError();

@@ -161,6 +161,8 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     if ((desc->k_layout != MILLION_KV_PAGED && desc->k_layout != MILLION_KV_ROWMAJOR) ||
         (desc->v_layout != MILLION_KV_PAGED && desc->v_layout != MILLION_KV_ROWMAJOR)) { set_error("attn: k_layout=%d v_layout=%d", desc->k_layout, desc->v_layout); return MILLION_ERR_ARG; }
     p.page_size = desc->page_size; p.n_pages_cap = desc->n_pages_cap; p.ids64 = desc->page_ids_i64;
+    p.v_identity = desc->v_pages_dense != 0;
+    if (p.v_identity && !p.v_paged) { set_error("attn: v_pages_dense needs v_layout = PAGED"); return MILLION_ERR_ARG; }
     p.ps_shift = p.page_size == 32 ? 5 : p.page_size == 64 ? 6 : 7;
     if (p.k_paged || p.v_paged) {
         if (p.page_size != 32 && p.page_size != 64 && p.page_size != 128) { set_error("attn: page_size=%d (32, 64, 128)", p.page_size); return MILLION_ERR_SHAPE; }
@@ -201,7 +203,7 @@ int million_version(void) { return MILLION_HIP_VERSION; }
 const char *million_last_error(void) { return g_err; }
 void million_set_force_generic(int on) {
     g_force_generic = (on == 1);
-    million::set_mfma_policy(on == 2 ? 1 : on == 3 ? 2 : 0);
+    million::set_mfma_policy(on == 2 ? 1 : 0);
 }
 void million_debug_set_stamp_buffer(void *buf) { g_dbg = (unsigned long long *)buf; }
 int million_debug_rows_reduce(const float *in64, float *out_max64, float *out_sum64, million_stream_t stream) {
@@ -223,19 +225,18 @@ int million_prepare_cents(const void *cents, int M, int C, int d_m, void *prepar
     return MILLION_OK;
 }
 
-int million_pq_encode(const million_encode_desc *desc, const void *x, const void *cents, void *dst,
-                      const int32_t *page_ids, million_stream_t stream) {
-    if (!desc || desc->struct_size != sizeof(million_encode_desc)) { set_error("encode: bad desc / struct_size"); return MILLION_ERR_ARG; }
-    if (!x || !cents || !dst) { set_error("encode: null pointer"); return MILLION_ERR_ARG; }
-    EncParams p;
+static int fill_enc_params(const char *who, const million_encode_desc *desc, const void *x, const void *cents, void *dst,
+                           const int32_t *page_ids, EncParams &p) {
+    if (!desc || desc->struct_size != sizeof(million_encode_desc)) { set_error("%s: bad desc / struct_size", who); return MILLION_ERR_ARG; }
+    if (!x || !cents || !dst) { set_error("%s: null pointer", who); return MILLION_ERR_ARG; }
     memset(&p, 0, sizeof(p));
     p.x = (const f16 *)x; p.cents = (const f16 *)cents; p.dst = (uint8_t *)dst; p.page_ids = page_ids;
-    if (desc->cents_prepared)
+    if (desc->cents_prepared && desc->C <= 256)
         p.cents32 = (const float *)((const f16 *)desc->cents_prepared + 2 * (size_t)desc->M * desc->C * (desc->d / (desc->M > 0 ? desc->M : 1)));
     p.bs = desc->bs; p.nh_k = desc->nh_k; p.n = desc->n; p.d = desc->d; p.M = desc->M; p.C = desc->C;
-    if (p.bs <= 0 || p.nh_k <= 0 || p.n < 0) { set_error("encode: bs=%d nh_k=%d n=%d", p.bs, p.nh_k, p.n); return MILLION_ERR_SHAPE; }
-    if (p.M <= 0 || p.d <= 0 || p.d % p.M) { set_error("encode: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
-    if (p.C < 1 || p.C > 256) { set_error("encode: C=%d (uint8 codes)", p.C); return MILLION_ERR_SHAPE; }
+    if (p.bs <= 0 || p.nh_k <= 0 || p.n < 0) { set_error("%s: bs=%d nh_k=%d n=%d", who, p.bs, p.nh_k, p.n); return MILLION_ERR_SHAPE; }
+    if (p.M <= 0 || p.d <= 0 || p.d % p.M) { set_error("%s: d=%d M=%d", who, p.d, p.M); return MILLION_ERR_SHAPE; }
+    if (p.C < 1 || p.C > 65536) { set_error("%s: C=%d (uint8 codes up to 256, uint16 codes up to 65536)", who, p.C); return MILLION_ERR_SHAPE; }
     p.dm = p.d / p.M;
     p.xsb = desc->x_stride_b; p.xsh = desc->x_stride_h; p.xsn = desc->x_stride_n;
     p.xrow_start = desc->x_row_start; p.xrow_mod = desc->x_row_mod;
@@ -244,21 +245,58 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
     p.page_size = desc->page_size; p.n_pages_cap = desc->n_pages_cap;
     p.dev_lengths = desc->dev_lengths;
     if (p.layout != MILLION_CODES_ROWMAJOR) {
-        if (p.layout != MILLION_CODES_KPAGES && p.layout != MILLION_CODES_VPAGES) { set_error("encode: dst_layout=%d", p.layout); return MILLION_ERR_ARG; }
-        if (!page_ids || p.page_size <= 0) { set_error("encode: paged destination needs page_ids and page_size"); return MILLION_ERR_ARG; }
-        if (!p.dev_lengths && (long long)p.n_pages_cap * p.page_size < (long long)p.tok0 + p.n) { set_error("encode: page table too short"); return MILLION_ERR_ARG; }
+        if (p.layout != MILLION_CODES_KPAGES && p.layout != MILLION_CODES_VPAGES) { set_error("%s: dst_layout=%d", who, p.layout); return MILLION_ERR_ARG; }
+        if (!page_ids || p.page_size <= 0) { set_error("%s: paged destination needs page_ids and page_size", who); return MILLION_ERR_ARG; }
+        if (!p.dev_lengths && (long long)p.n_pages_cap * p.page_size < (long long)p.tok0 + p.n) { set_error("%s: page table too short", who); return MILLION_ERR_ARG; }
     }
-    if (p.tok0 < 0) { set_error("encode: dst_token_start=%d", p.tok0); return MILLION_ERR_ARG; }
+    if (p.tok0 < 0) { set_error("%s: dst_token_start=%d", who, p.tok0); return MILLION_ERR_ARG; }
+    return MILLION_OK;
+}
+
+int million_pq_encode(const million_encode_desc *desc, const void *x, const void *cents, void *dst,
+                      const int32_t *page_ids, million_stream_t stream) {
+    EncParams p;
+    const int rc = fill_enc_params("encode", desc, x, cents, dst, page_ids, p);
+    if (rc != MILLION_OK) return rc;
     return launch_encode(p, (hipStream_t)stream);
+}
+
+int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const void *v_rows, const void *k_cents,
+                     const void *v_cents, void *k_pool, void *v_pool, const int32_t *page_ids, int32_t *dev_lengths,
+                     int resid_cap, million_stream_t stream) {
+    EncParams k, v;
+    int rc = fill_enc_params("flush", desc, k_rows, k_cents, k_pool, page_ids, k);
+    if (rc != MILLION_OK) return rc;
+    rc = fill_enc_params("flush", desc, v_rows, v_cents, v_pool, page_ids, v);
+    if (rc != MILLION_OK) return rc;
+    if (k.C > 256) { set_error("flush: uint8 codes only (C=%d)", k.C); return MILLION_ERR_SHAPE; }
+    if (desc->dst_layout != MILLION_CODES_KPAGES) { set_error("flush: dst_layout must be MILLION_CODES_KPAGES (the V side is written as VPAGES)"); return MILLION_ERR_ARG; }
+    if (resid_cap <= 0) { set_error("flush: resid_cap=%d", resid_cap); return MILLION_ERR_ARG; }
+    if ((const int32_t *)dev_lengths != desc->dev_lengths) { set_error("flush: dev_lengths must equal desc->dev_lengths (or both null)"); return MILLION_ERR_ARG; }
+    v.layout = MILLION_CODES_VPAGES;
+    return launch_flush(k, v, dev_lengths, resid_cap, (hipStream_t)stream);
 }
 
 int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n_rows, int d, int M, int C,
                       million_stream_t stream) {
     if (n_rows < 0 || M <= 0 || d <= 0 || d % M) { set_error("decode: n_rows=%lld d=%d M=%d", (long long)n_rows, d, M); return MILLION_ERR_SHAPE; }
-    if (C < 1 || C > 256) { set_error("decode: C=%d (uint8 codes)", C); return MILLION_ERR_SHAPE; }
+    if (C < 1 || C > 65536) { set_error("decode: C=%d (uint8 codes up to 256, uint16 codes up to 65536)", C); return MILLION_ERR_SHAPE; }
     if (n_rows == 0) return MILLION_OK;
     if (!codes || !cents || !out) { set_error("decode: null pointer"); return MILLION_ERR_ARG; }
-    return launch_decode((const uint8_t *)codes, (const f16 *)cents, (f16 *)out, n_rows, M, C, d / M, (hipStream_t)stream);
+    return launch_decode(codes, (const f16 *)cents, (f16 *)out, n_rows, M, C, d / M, (hipStream_t)stream);
+}
+
+int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh_k, int n_tokens, int M,
+                              int64_t v_stride_b, int64_t v_stride_h, million_stream_t stream) {
+    if (!v_codes || !v_pages) { set_error("transpose_v_codes: null pointer"); return MILLION_ERR_ARG; }
+    if (bs <= 0 || nh_k <= 0 || n_tokens <= 0 || M <= 0 || M > 64 || M % 16) { set_error("transpose_v_codes: bs=%d nh_k=%d T=%d M=%d", bs, nh_k, n_tokens, M); return MILLION_ERR_SHAPE; }
+    if ((((uintptr_t)v_codes | (uintptr_t)v_pages) & 15) || ((v_stride_b | v_stride_h) & 15)) { set_error("transpose_v_codes: 16-byte alignment"); return MILLION_ERR_ALIGN; }
+    const int n_pages = (n_tokens + 63) / 64;
+    hipLaunchKernelGGL(codes_transpose_kernel, dim3(n_pages, bs * nh_k), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)v_codes, (uint8_t *)v_pages, nh_k, n_tokens, M, (long long)v_stride_b, (long long)v_stride_h, n_pages);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
 }
 
 size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
@@ -301,7 +339,7 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     }
     if (!q || !k_cents_prepared || !v_cents_prepared || !k_resid || !v_resid || !out || !workspace) { set_error("attn: null pointer"); return MILLION_ERR_ARG; }
     if (p.T > 0 && (!k_codes || !v_codes)) { set_error("attn: null code pointer with n_tokens=%d", p.T); return MILLION_ERR_ARG; }
-    if (p.T > 0 && ((p.k_paged && !k_page_ids) || (p.v_paged && !v_page_ids))) { set_error("attn: paged layout without page ids"); return MILLION_ERR_ARG; }
+    if (p.T > 0 && ((p.k_paged && !k_page_ids) || (p.v_paged && !p.v_identity && !v_page_ids))) { set_error("attn: paged layout without page ids"); return MILLION_ERR_ARG; }
     if (workspace_bytes < million_attn_workspace_bytes(desc)) { set_error("attn: workspace %zu < %zu bytes", workspace_bytes, million_attn_workspace_bytes(desc)); return MILLION_ERR_WORKSPACE; }
     if (((uintptr_t)q | (uintptr_t)k_codes | (uintptr_t)v_codes | (uintptr_t)k_resid | (uintptr_t)v_resid |
          (uintptr_t)out | (uintptr_t)workspace | (uintptr_t)k_cents_prepared | (uintptr_t)v_cents_prepared) & 15) {

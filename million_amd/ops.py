@@ -69,8 +69,9 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
     faster; the codes are bit-identical either way.  prepared: that blob, when the caller already holds it (the caches
     do: nothing is allocated or launched on their behalf inside a captured step)."""
     _need_cuda(X, cents, dst, page_ids)
-    if X.dtype != torch.float16 or cents.dtype != torch.float16 or dst.dtype != torch.uint8:
-        raise RuntimeError("pq_encode: X and cents must be fp16, dst uint8")
+    code_dtype = code_dtype_for(cents.shape[1])
+    if X.dtype != torch.float16 or cents.dtype != torch.float16 or dst.dtype != code_dtype:
+        raise RuntimeError(f"pq_encode: X and cents must be fp16, dst {code_dtype} for C={cents.shape[1]}")
     if X.dim() != 4 or X.stride(3) != 1:
         raise RuntimeError("pq_encode: X must be (bs, nh_k, n, d) with a contiguous last dim")
     cents = cents.contiguous()
@@ -88,7 +89,7 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
             raise RuntimeError("pq_encode: row-major dst must be (bs, nh_k, T_cap, M) with dense rows")
         if dst.shape[2] < token_start + n:
             raise RuntimeError("pq_encode: dst too short")
-        desc.dst_stride_b, desc.dst_stride_h = dst.stride(0), dst.stride(1)
+        desc.dst_stride_b, desc.dst_stride_h = dst.stride(0) * dst.element_size(), dst.stride(1) * dst.element_size()
     else:
         if page_ids is None or page_ids.dtype != torch.int32 or not page_ids.is_contiguous():
             raise RuntimeError("pq_encode: paged dst needs contiguous int32 page_ids (bs, nh_k, n_pages_cap)")
@@ -96,7 +97,7 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
             raise RuntimeError("pq_encode: page pool must be contiguous")
         desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
     desc.dev_lengths = _ptr(dev_lengths)
-    if prepared is None and use_prepared:
+    if prepared is None and use_prepared and C <= 256:
         prepared = prepare_cents(cents)            # cached per codebook tensor; callers that own one pass it in
     desc.cents_prepared = _ptr(prepared)
     lib = L.load()
@@ -105,12 +106,14 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
 
 
 def pq_decode(codes: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
-    """Drop-in for sa_decode_4d (reference pq_utils.py:501-540): codes (..., M) u8 + (M, C, d_m) fp16 codebook ->
-    (..., d) fp16 reconstruction (exact gather)."""
+    """Drop-in for sa_decode_4d (reference pq_utils.py:501-540): codes (..., M) u8 (u16 for C > 256) + (M, C, d_m) fp16
+    codebook -> (..., d) fp16 reconstruction (exact gather)."""
     _need_cuda(codes, cents)
-    if codes.dtype != torch.uint8 or cents.dtype != torch.float16 or cents.dim() != 3:
-        raise RuntimeError("pq_decode: codes must be uint8 and cents fp16 (M, C, d_m)")
+    if cents.dtype != torch.float16 or cents.dim() != 3:
+        raise RuntimeError("pq_decode: cents must be fp16 (M, C, d_m)")
     M, C, dm = cents.shape
+    if codes.dtype != code_dtype_for(C):
+        raise RuntimeError(f"pq_decode: codes must be {code_dtype_for(C)} for C={C}, got {codes.dtype}")
     if codes.shape[-1] != M:
         raise RuntimeError(f"pq_decode: codes have {codes.shape[-1]} subspaces, codebook {M}")
     codes, cents = codes.contiguous(), cents.contiguous()
@@ -121,13 +124,97 @@ def pq_decode(codes: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def code_dtype_for(C: int):
+    """nbits2dtype of the reference (pq_utils.py:542-552) in terms of the codebook size: uint8 up to 256 centroids,
+    uint16 up to 65536."""
+    if C <= 256:
+        return torch.uint8
+    if C <= 65536:
+        return torch.uint16
+    raise RuntimeError(f"codebooks of {C} centroids are not supported (<= 65536)")
+
+
 def pq_encode(X: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
-    """Drop-in for sa_encode_4d_keops (reference pq_utils.py:451-499): (bs, nh_k, n, d) -> (bs, nh_k, n, M) u8."""
+    """Drop-in for sa_encode_4d_keops (reference pq_utils.py:451-499): (bs, nh_k, n, d) -> (bs, nh_k, n, M) u8 (u16 for
+    nbits 9..16, as sa_encode_4d_keops(target_dtype=nbits2dtype(nbits)) returns)."""
     bs, nhk, n, d = X.shape
-    codes = torch.empty(bs, nhk, n, cents.shape[0], dtype=torch.uint8, device=X.device)
+    codes = torch.empty(bs, nhk, n, cents.shape[0], dtype=code_dtype_for(cents.shape[1]), device=X.device)
     if n:
         pq_encode_into(X, cents, codes)
     return codes
+
+
+def pq_flush(k_rows: torch.Tensor, v_rows: torch.Tensor, k_cents: torch.Tensor, v_cents: torch.Tensor,
+             k_pool: torch.Tensor, v_pool: torch.Tensor, page_ids: torch.Tensor, *, n: int, page_size: int,
+             token_start: int = 0, x_row_start: int = 0, dev_lengths: Optional[torch.Tensor] = None) -> None:
+    """One launch per window flush (reference PagedPQCache.flush_to_pages, paged_pq_utils.py:130-210): encode the oldest n
+    rows of the K and V windows (rings of k_rows.shape[2] rows) into a K page and a transposed V page; with dev_lengths
+    the destination token and the ring start are read on the device and advanced there."""
+    _need_cuda(k_rows, v_rows, k_cents, v_cents, k_pool, v_pool, page_ids, dev_lengths)
+    if k_rows.shape != v_rows.shape or k_rows.stride() != v_rows.stride() or k_rows.dtype != torch.float16 or v_rows.dtype != torch.float16:
+        raise RuntimeError("pq_flush: K and V windows must be fp16 with the same shape and strides")
+    if k_rows.dim() != 4 or k_rows.stride(3) != 1:
+        raise RuntimeError("pq_flush: windows must be (bs, nh_k, cap, d) with a contiguous last dim")
+    if page_ids.dtype != torch.int32 or not page_ids.is_contiguous() or not k_pool.is_contiguous() or not v_pool.is_contiguous():
+        raise RuntimeError("pq_flush: contiguous pools and contiguous int32 page_ids (bs, nh_k, n_pages_cap) expected")
+    k_cents, v_cents = k_cents.contiguous(), v_cents.contiguous()
+    bs, nhk, cap, d = k_rows.shape
+    M, C, dm = k_cents.shape
+    if v_cents.shape != k_cents.shape or C > 256 or k_pool.dtype != torch.uint8 or v_pool.dtype != torch.uint8:
+        raise RuntimeError("pq_flush: uint8 codes, equal codebook shapes")
+    desc = L.EncodeDesc()
+    desc.struct_size = ctypes.sizeof(L.EncodeDesc)
+    desc.bs, desc.nh_k, desc.n, desc.d, desc.M, desc.C = bs, nhk, n, d, M, C
+    desc.x_stride_b, desc.x_stride_h, desc.x_stride_n = k_rows.stride(0), k_rows.stride(1), k_rows.stride(2)
+    desc.x_row_start, desc.x_row_mod = x_row_start, cap
+    desc.dst_layout, desc.dst_token_start = L.MILLION_CODES_KPAGES, token_start
+    desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
+    desc.dev_lengths = _ptr(dev_lengths)
+    L.check(L.load().million_pq_flush(ctypes.byref(desc), k_rows.data_ptr(), v_rows.data_ptr(), k_cents.data_ptr(),
+                                      v_cents.data_ptr(), k_pool.data_ptr(), v_pool.data_ptr(), page_ids.data_ptr(),
+                                      _ptr(dev_lengths), cap, _stream()), "million_pq_flush")
+
+
+def transpose_v_codes(v_codes: torch.Tensor, n_tokens: Optional[int] = None) -> torch.Tensor:
+    """Row-major V codes (bs, nh_k, T, M) u8 -> dense transposed 64-token pages ((bs*nh_k)*ceil(T/64), M, 64)."""
+    _need_cuda(v_codes)
+    if v_codes.dtype != torch.uint8 or v_codes.dim() != 4:
+        raise RuntimeError("transpose_v_codes: (bs, nh_k, T, M) uint8 expected")
+    bs, nhk, T, M = v_codes.shape
+    T = T if n_tokens is None else n_tokens
+    if T <= 0 or v_codes.stride(3) != 1 or v_codes.stride(2) != M:
+        raise RuntimeError("transpose_v_codes: dense rows and T > 0 expected")
+    pages = torch.empty(bs * nhk * ((T + 63) // 64), M, 64, dtype=torch.uint8, device=v_codes.device)
+    L.check(L.load().million_transpose_v_codes(v_codes.data_ptr(), pages.data_ptr(), bs, nhk, T, M, v_codes.stride(0),
+                                               v_codes.stride(1), _stream()), "million_transpose_v_codes")
+    return pages
+
+
+# Transposed shadow of row-major V code tensors.  The reference's production call (Interface.template.cu:26-38) hands the
+# SAME value_codes tensor to the kernel on every decode step between two flushes (DynamicPQCache.value_cache[layer] is
+# replaced by torch.cat only when the window is flushed, pq_utils.py:140-147).  The fast kernels want transposed pages, so
+# the first call on a tensor transposes it once and later calls reuse the pages.  Keyed on the tensor OBJECT (weak
+# reference, so a new tensor at a recycled address never hits) + its version counter (in-place writes through torch
+# invalidate) + geometry; bounded (least recently used) so abandoned tensors do not pin memory.
+_vshadow: "dict[int, tuple]" = {}
+_VSHADOW_MAX = 128
+
+
+def _v_pages_of(v_codes: torch.Tensor, n_tokens: int) -> torch.Tensor:
+    key = id(v_codes)
+    sig = (v_codes._version, n_tokens, tuple(v_codes.shape), v_codes.stride(), v_codes.data_ptr())
+    hit = _vshadow.get(key)
+    if hit is not None and hit[0]() is v_codes and hit[1] == sig:
+        _vshadow[key] = _vshadow.pop(key)          # most recently used last
+        return hit[2]
+    pages = transpose_v_codes(v_codes, n_tokens)
+    for k in [k for k, v in _vshadow.items() if v[0]() is None]:
+        del _vshadow[k]
+    while len(_vshadow) >= _VSHADOW_MAX:
+        del _vshadow[next(iter(_vshadow))]
+    _vshadow.pop(key, None)
+    _vshadow[key] = (weakref.ref(v_codes), sig, pages)
+    return pages
 
 
 def attn_workspace(desc: L.AttnDesc, device: torch.device) -> torch.Tensor:
@@ -145,7 +232,7 @@ def attn_workspace(desc: L.AttnDesc, device: torch.device) -> torch.Tensor:
 
 def make_attn_desc(q, k_res, *, nh_k, M, C, n_tokens, r, resid_start=0, k_paged=False, v_paged=False,
                    page_size=0, n_pages_cap=0, page_ids_i64=False, k_codes=None, v_codes=None,
-                   dev_lengths=None) -> L.AttnDesc:
+                   dev_lengths=None, v_pages_dense=False) -> L.AttnDesc:
     bs, nh, _, d = q.shape
     desc = L.AttnDesc()
     desc.struct_size = ctypes.sizeof(L.AttnDesc)
@@ -155,6 +242,7 @@ def make_attn_desc(q, k_res, *, nh_k, M, C, n_tokens, r, resid_start=0, k_paged=
     desc.k_layout = L.MILLION_KV_PAGED if k_paged else L.MILLION_KV_ROWMAJOR
     desc.v_layout = L.MILLION_KV_PAGED if v_paged else L.MILLION_KV_ROWMAJOR
     desc.page_size, desc.n_pages_cap, desc.page_ids_i64 = page_size, n_pages_cap, int(page_ids_i64)
+    desc.v_pages_dense = int(v_pages_dense)
     if not k_paged and k_codes is not None:
         desc.k_stride_b, desc.k_stride_h = k_codes.stride(0), k_codes.stride(1)
     if not v_paged and v_codes is not None:
@@ -221,9 +309,16 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
             raise RuntimeError("pq_decode_attn: V page pool must be contiguous")
     else:
         _check_rowmajor("value_codes", v_codes, M, n_tokens)
+    v_dense = False
+    if (not v_paged and not k_paged and n_tokens > 0 and C == 256 and q.shape[3] == 128 and M in (32, 64)
+            and k_res.shape[2] <= 128 and q.shape[1] // nh_k <= 8 and dev_lengths is None):
+        # the reference's 10-argument layout on the fast shapes: transposed pages of V, made once per code tensor
+        v_codes = _v_pages_of(v_codes, n_tokens)
+        v_paged, v_dense, page_size, n_pages_cap = True, True, 64, (n_tokens + 63) // 64
     desc = make_attn_desc(q, k_res, nh_k=nh_k, M=M, C=C, n_tokens=n_tokens, r=r, resid_start=resid_start,
                           k_paged=k_paged, v_paged=v_paged, page_size=page_size, n_pages_cap=n_pages_cap,
-                          page_ids_i64=ids64, k_codes=k_codes, v_codes=v_codes, dev_lengths=dev_lengths)
+                          page_ids_i64=ids64, k_codes=k_codes, v_codes=None if v_dense else v_codes,
+                          dev_lengths=dev_lengths, v_pages_dense=v_dense)
     if out is None:
         out = torch.empty_like(q)
     ws = workspace if workspace is not None else attn_workspace(desc, q.device)

@@ -173,8 +173,13 @@ class _CacheBase:
         """cent is (M, C, d//M) — one table shared by all layers and heads (pq_utils.py:149-159)."""
         self.key_cent = key_cent.to(self.device, self.scalar_t).contiguous()
         self.value_cent = self.key_cent if value_cent is key_cent else value_cent.to(self.device, self.scalar_t).contiguous()
-        self._kprep = ops.prepare_cents(self.key_cent, cache=False)
-        self._vprep = self._kprep if self.value_cent is self.key_cent else ops.prepare_cents(self.value_cent, cache=False)
+        if self.key_cent.shape[1] != self.C or self.value_cent.shape[1] != self.C:
+            raise ValueError(f"codebooks must have 2**nbits = {self.C} centroids per subspace")
+        if self.C <= 256:      # LDS-ready images for the fused decode kernels and the fp32 image for the encoder
+            self._kprep = ops.prepare_cents(self.key_cent, cache=False)
+            self._vprep = self._kprep if self.value_cent is self.key_cent else ops.prepare_cents(self.value_cent, cache=False)
+        else:
+            self._kprep = self._vprep = None
 
     def _prefill_attention(self, q, k, v):
         """Prefill attention is outside the PQ hot path (reference: torch SDPA, pq_utils.py:249-260)."""
@@ -189,10 +194,16 @@ class DynamicPQCache(_CacheBase):
     """Row-major code store + residual window of Lt=d rows; flush ALL Lt rows when full
     (reference pq_utils.py:98-328).  `max_tokens` bounds the preallocated store."""
 
-    def __init__(self, *, bs, nh, num_key_value_heads, M, layer_num, dtype=torch.uint8, nbits=8, d=128,
+    def __init__(self, *, bs, nh, num_key_value_heads, M, layer_num, dtype=None, nbits=8, d=128,
                  scalar_t=torch.float16, max_tokens=32768 + 1024, device="cuda"):
-        if nbits != 8 or dtype != torch.uint8:
-            raise NotImplementedError("Only uint8 code type is supported for now")
+        # nbits <= 8: uint8 codes, every path.  nbits 9..16: uint16 codes (nbits2dtype, pq_utils.py:542-552) on the
+        # dequantise-then-attend paths (update, prefill); the fused decode kernels are uint8-only, as the reference's
+        # are (KernelRegistry raises NotImplementedError, pq_utils.py:50-52).
+        if not 1 <= nbits <= 16:
+            raise NotImplementedError("nbits must be in 1..16")
+        dtype = nbits2dtype(nbits) if dtype is None else dtype
+        if dtype != nbits2dtype(nbits):
+            raise ValueError(f"dtype {dtype} does not match nbits={nbits} ({nbits2dtype(nbits)})")
         self.bs, self.nh, self.num_key_value_heads, self.M, self.layer_num = bs, nh, num_key_value_heads, M, layer_num
         self.dtype, self.nbits, self.d, self.scalar_t, self.device = dtype, nbits, d, scalar_t, torch.device(device)
         self.C = 2 ** nbits
@@ -204,8 +215,8 @@ class DynamicPQCache(_CacheBase):
     def init_cache(self):
         z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=self.device)
         nk, Lt = self.num_key_value_heads, self.max_residual_length
-        self._k_store = [z(self.bs, nk, self.max_tokens, self.M, dt=torch.uint8) for _ in range(self.layer_num)]
-        self._v_store = [z(self.bs, nk, self.max_tokens, self.M, dt=torch.uint8) for _ in range(self.layer_num)]
+        self._k_store = [z(self.bs, nk, self.max_tokens, self.M, dt=self.dtype) for _ in range(self.layer_num)]
+        self._v_store = [z(self.bs, nk, self.max_tokens, self.M, dt=self.dtype) for _ in range(self.layer_num)]
         self.key_residual_cache = [z(self.bs, nk, Lt, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
         self.value_residual_cache = [z(self.bs, nk, Lt, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
         self.seen_tokens = [0] * self.layer_num
@@ -263,6 +274,8 @@ class DynamicPQCache(_CacheBase):
         """One decode step of one layer (pq_utils.py:281-328).  fused=True (default): append + attention in ONE launch.
         fused=False: the reference's own call sequence - copy the new row into the window (:304-312), then the kernel
         `registery.get_kernel(l=seen_tokens)` resolves by name from `bindings` (:315-325)."""
+        if self.nbits > 8:
+            raise NotImplementedError("Only uint8 code type is supported by the fused decode kernels (use update())")
         Lt = self.max_residual_length
         if self.residualed_tokens[layer_idx] == Lt:                        # pq_utils.py:288-302
             self._append_codes((self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx]), layer_idx, Lt)
@@ -291,7 +304,7 @@ class DynamicPQCache(_CacheBase):
 
     @property
     def pq_cache_size(self):
-        return sum(2 * self.bs * self.num_key_value_heads * t * self.M for t in self._T)
+        return sum(2 * self.bs * self.num_key_value_heads * t * self.M * self._k_store[0].element_size() for t in self._T)
 
     @property
     def residual_cache_size(self):
@@ -392,13 +405,20 @@ class PagedPQCache(_CacheBase):
         return self._prefill_attention(query_states, key_states, value_states)
 
     def flush_to_pages(self, layer_idx: int, use_dev_lengths=False):
-        """Encode the oldest page_size residual rows into a new K page and V page (paged_pq_utils.py:130-210)."""
+        """Encode the oldest page_size residual rows into a new K page and V page and move the window on
+        (paged_pq_utils.py:130-210) - ONE launch (million_pq_flush): K encode, V encode and, with device-resident
+        lengths, their advance."""
         if self.residualed_tokens[layer_idx] < self.page_size:
             return
-        self._encode_to_pages(self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], layer_idx,
-                              self.page_size, from_ring=True, use_dev_lengths=use_dev_lengths)
-        if use_dev_lengths:
-            ops.lengths_advance(self.lengths[layer_idx], self.page_size, self.extended_residual_size)
+        T = self._T[layer_idx]
+        if not self.preallocate:
+            self._assign_pages(layer_idx, (T + self.page_size + self.page_size - 1) // self.page_size)
+        elif T + self.page_size > self.max_tokens:
+            raise RuntimeError(f"PagedPQCache: {T + self.page_size} tokens exceed max_tokens={self.max_tokens}")
+        ops.pq_flush(self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], self.key_cent,
+                     self.value_cent, self.key_page_pool, self.value_page_pool, self.page_ids[layer_idx],
+                     n=self.page_size, page_size=self.page_size, token_start=T, x_row_start=self._rstart[layer_idx],
+                     dev_lengths=self.lengths[layer_idx] if use_dev_lengths else None)
         self._T[layer_idx] += self.page_size
         self.residualed_tokens[layer_idx] -= self.page_size
         self._rstart[layer_idx] = (self._rstart[layer_idx] + self.page_size) % self.extended_residual_size

@@ -768,3 +768,164 @@ def test_dynamic_cache_decoding_through_registry(env, oracle):
         if not fused:
             assert sorted(cache.registery.kernels) == [2, 4]      # l2Ns(71..128) = 2, l2Ns(129..210) = 4
     assert np.abs(outs[True] - outs[False]).max() < 2e-3
+
+
+# ---- nbits 9..16: uint16 codes (reference nbits2dtype pq_utils.py:542-552, update :166-220) --------------
+@pytest.mark.parametrize("case", synth.GOLDEN_ENCODE_U16, ids=[c[0] for c in synth.GOLDEN_ENCODE_U16])
+def test_encode_decode_u16_bit_exact(case, env, oracle, golden_dir):
+    torch, ops = env
+    name, seed, bs, nhk, n, d, M, C = case
+    c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+    Xd, cd = torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["cents"]).cuda()
+    codes = ops.pq_encode(Xd, cd)
+    assert codes.dtype == torch.uint16 and codes.shape == (bs, nhk, n, M)
+    gold = oracle.pq_encode(c["X"], c["cents"])
+    np.testing.assert_array_equal(codes.cpu().numpy(), gold)
+    # the reference's own sa_encode_4d(target_dtype=uint16) output: near-tie flips of the cdist form only
+    fix = np.load(golden_dir / f"encode_{name}.npz")
+    assert (codes.cpu().numpy() != fix["codes"]).sum() <= 1
+    dec = ops.pq_decode(torch.from_numpy(fix["codes"]).cuda(), cd)
+    np.testing.assert_array_equal(dec.cpu().numpy().view(np.uint16), fix["decoded"].view(np.uint16))
+    with pytest.raises(RuntimeError):
+        ops.pq_decode(torch.zeros(1, 1, 1, M, dtype=torch.uint8, device="cuda"), cd)      # wrong code width for C > 256
+
+
+def test_encode_u16_layouts_and_big(env, oracle):
+    """uint16 codes in the three destination layouts, ragged sizes, d_m = 2 and 4, C = 512 / 4096."""
+    torch, ops = env
+    from million_amd import _lib as L
+    for (M, C, n, seed) in ((64, 512, 300, 1), (32, 4096, 70, 2)):
+        rs = np.random.RandomState(seed)
+        d = 128
+        cents = rs.standard_normal((M, C, d // M)).astype(np.float16)
+        cents[:, C - 1] = cents[:, 5]                  # exact duplicates: lower index must win
+        X = rs.standard_normal((2, 2, n, d)).astype(np.float16)
+        X[0, 0, :3] = cents[:, 5].reshape(-1)
+        gold = oracle.pq_encode(X, cents)
+        assert gold.dtype == np.uint16 and (gold[0, 0, :3] == 5).all() and gold.max() > 255
+        Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(cents).cuda()
+        np.testing.assert_array_equal(ops.pq_encode(Xd, cd).cpu().numpy(), gold)
+        ps, t0 = 64, 64
+        n_pages = (t0 + n + ps - 1) // ps
+        ids = torch.arange(2 * 2 * n_pages, dtype=torch.int32).reshape(2, 2, n_pages).flip(2).contiguous().cuda()
+        kpool = torch.zeros(2 * 2 * n_pages, ps, M, dtype=torch.uint16).cuda()
+        vpool = torch.zeros(2 * 2 * n_pages, M, ps, dtype=torch.uint16).cuda()
+        ops.pq_encode_into(Xd, cd, kpool, layout=L.MILLION_CODES_KPAGES, token_start=t0, page_ids=ids, page_size=ps)
+        ops.pq_encode_into(Xd, cd, vpool, layout=L.MILLION_CODES_VPAGES, token_start=t0, page_ids=ids, page_size=ps)
+        kp, vp, idn = kpool.cpu().numpy(), vpool.cpu().numpy(), ids.cpu().numpy()
+        for b in range(2):
+            for h in range(2):
+                toks = np.arange(n) + t0
+                pid = idn[b, h, toks // ps]
+                np.testing.assert_array_equal(kp[pid, toks % ps], gold[b, h])
+                np.testing.assert_array_equal(vp[pid, :, toks % ps], gold[b, h])
+        # decode of wide codes == the oracle's gather
+        dec = ops.pq_decode(torch.from_numpy(gold).cuda(), cd)
+        np.testing.assert_array_equal(dec.cpu().numpy(), oracle.pq_decode_numpy(gold, cents).astype(np.float16))
+
+
+def test_dynamic_cache_nbits10_update(env, oracle):
+    """DynamicPQCache(nbits=10): uint16 code store; update / prefill(distort_recent) (pq_utils.py:166-260) against the
+    oracle; the fused decode kernels refuse (uint8 only, as the reference's KernelRegistry, pq_utils.py:50-52)."""
+    torch, ops = env
+    from million_amd.pq_cache import DynamicPQCache, nbits2dtype
+    bs, nh, nhk, M, d, nbits = 1, 8, 2, 64, 128, 10
+    rs = np.random.RandomState(41)
+    ck = rs.standard_normal((M, 2 ** nbits, d // M)).astype(np.float16)
+    cv = rs.standard_normal((M, 2 ** nbits, d // M)).astype(np.float16)
+    cache = DynamicPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, nbits=nbits, max_tokens=256)
+    assert cache.dtype == nbits2dtype(nbits) == torch.uint16
+    cache.set_cent(torch.from_numpy(ck).cuda(), torch.from_numpy(cv).cuda())
+    k1, v1 = rs.standard_normal((bs, nhk, 50, d)).astype(np.float16), rs.standard_normal((bs, nhk, 50, d)).astype(np.float16)
+    k2, v2 = rs.standard_normal((bs, nhk, 2, d)).astype(np.float16), rs.standard_normal((bs, nhk, 2, d)).astype(np.float16)
+    dq = lambda x, c: oracle.pq_decode_numpy(oracle.pq_encode(x, c), c)
+    cache.update(torch.from_numpy(k1).cuda(), torch.from_numpy(v1).cuda(), 0)
+    K, V = cache.update(torch.from_numpy(k2).cuda(), torch.from_numpy(v2).cuda(), 0)
+    np.testing.assert_array_equal(K.cpu().numpy(), np.concatenate([dq(k1, ck), k2], axis=2))
+    np.testing.assert_array_equal(V.cpu().numpy(), np.concatenate([dq(v1, cv), v2], axis=2))
+    assert cache.key_cache[0].dtype == torch.uint16 and cache.key_cache[0].shape == (bs, nhk, 52, M)
+    np.testing.assert_array_equal(cache.key_cache[0].cpu().numpy(), oracle.pq_encode(np.concatenate([k1, k2], axis=2), ck))
+    K, V = cache.update(torch.from_numpy(k2).cuda(), torch.from_numpy(v2).cuda(), 0, distort_recent=True)
+    np.testing.assert_array_equal(V.cpu().numpy(), np.concatenate([dq(v1, cv), dq(v2, cv), dq(v2, cv)], axis=2))
+    with pytest.raises(NotImplementedError):
+        cache.decoding(torch.zeros(bs, nh, 1, d, dtype=torch.float16, device="cuda"), torch.from_numpy(k2[:, :, :1]).cuda(),
+                       torch.from_numpy(v2[:, :, :1]).cuda(), 0)
+    with pytest.raises(ValueError):
+        DynamicPQCache(bs=1, nh=8, num_key_value_heads=2, M=M, layer_num=1, d=d, nbits=10, dtype=torch.uint8)
+
+
+def test_flush_one_launch_equals_separate_encodes(env, oracle):
+    """million_pq_flush (K encode + V encode + device-length advance in one launch) == two million_pq_encode calls +
+    million_lengths_advance, for host and device lengths, ring start in the middle of the window, batch 2."""
+    torch, ops = env
+    from million_amd import _lib as L
+    bs, nhk, d, M, C, ps, cap = 2, 3, 128, 64, 256, 64, 128
+    rs = np.random.RandomState(51)
+    ck = torch.from_numpy(rs.standard_normal((M, C, 2)).astype(np.float16)).cuda()
+    cv = torch.from_numpy(rs.standard_normal((M, C, 2)).astype(np.float16)).cuda()
+    kw = torch.from_numpy(rs.standard_normal((bs, nhk, cap, d)).astype(np.float16)).cuda()
+    vw = torch.from_numpy(rs.standard_normal((bs, nhk, cap, d)).astype(np.float16)).cuda()
+    n_pages = 6
+    ids = torch.randperm(bs * nhk * n_pages).to(torch.int32).reshape(bs, nhk, n_pages).cuda()
+    T0, start = 128, 70
+    for use_dl in (False, True):
+        pools = []
+        for fused in (False, True):
+            kpool = torch.zeros(bs * nhk * n_pages, ps, M, dtype=torch.uint8, device="cuda")
+            vpool = torch.zeros(bs * nhk * n_pages, M, ps, dtype=torch.uint8, device="cuda")
+            dl = torch.tensor([[T0, cap, start, 0]] * bs, dtype=torch.int32, device="cuda") if use_dl else None
+            if fused:
+                ops.pq_flush(kw, vw, ck, cv, kpool, vpool, ids, n=ps, page_size=ps, token_start=T0, x_row_start=start, dev_lengths=dl)
+            else:
+                kwargs = dict(token_start=T0, n=ps, page_ids=ids, page_size=ps, x_row_start=start, x_row_mod=cap, dev_lengths=dl)
+                ops.pq_encode_into(kw, ck, kpool, layout=L.MILLION_CODES_KPAGES, **kwargs)
+                ops.pq_encode_into(vw, cv, vpool, layout=L.MILLION_CODES_VPAGES, **kwargs)
+                if use_dl:
+                    ops.lengths_advance(dl, ps, cap)
+            torch.cuda.synchronize()
+            pools.append((kpool.cpu().numpy(), vpool.cpu().numpy(), None if dl is None else dl.cpu().numpy()))
+        np.testing.assert_array_equal(pools[0][0], pools[1][0])
+        np.testing.assert_array_equal(pools[0][1], pools[1][1])
+        if use_dl:
+            np.testing.assert_array_equal(pools[0][2], pools[1][2])
+            assert pools[1][2].tolist() == [[T0 + ps, cap - ps, (start + ps) % cap, 0]] * bs
+    # and against the oracle: page 2 of (b, hk) holds the codes of ring rows start .. start + 63
+    rows = (np.arange(ps) + start) % cap
+    gold = oracle.pq_encode(kw.cpu().numpy()[:, :, rows], ck.cpu().numpy())
+    idn = ids.cpu().numpy()
+    for b in range(bs):
+        for h in range(nhk):
+            np.testing.assert_array_equal(pools[1][0][idn[b, h, T0 // ps]], gold[b, h])
+
+
+def test_rowmajor_v_shadow_reuse_and_invalidation(env, oracle):
+    """The 10-argument layout (row-major V) on the fast shapes: the transposed pages of a V code tensor are made once and
+    reused while the same tensor object is passed (the reference passes value_cache[layer] unchanged between flushes);
+    an in-place write or a new tensor gets fresh pages."""
+    torch, ops = env
+    c = synth.attn_case(611, 1, 32, 8, 128, 64, 256, 3000, 40)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+    call = lambda vc: ops.pq_decode_attn(t["q"], t["k_codes"], vc, kp, vp, t["k_res"], t["v_res"], c["r"], M=64, C=256)
+    ops._vshadow.clear()
+    o1 = call(t["v_codes"])
+    pages = ops._vshadow[id(t["v_codes"])][2]
+    o2 = call(t["v_codes"])
+    assert ops._vshadow[id(t["v_codes"])][2] is pages and len(ops._vshadow) == 1      # reused, not re-made
+    torch.cuda.synchronize()
+    gold = oracle.decode_attn(**c)
+    _check(o1.cpu().numpy(), gold, "first call")
+    _check(o2.cpu().numpy(), gold, "second call (shadow hit)")
+    # in-place change of the codes (version counter moves): pages are rebuilt
+    t["v_codes"][:, :, 100:200] = 7
+    c2 = dict(c, v_codes=t["v_codes"].cpu().numpy())
+    o3 = call(t["v_codes"])
+    assert ops._vshadow[id(t["v_codes"])][2] is not pages
+    _check(o3.cpu().numpy(), oracle.decode_attn(**c2), "after in-place write")
+    # a different tensor object with equal content: its own entry
+    v2 = t["v_codes"].clone()
+    _check(call(v2).cpu().numpy(), oracle.decode_attn(**c2), "clone")
+    assert len(ops._vshadow) == 2
+    del v2
+    call(t["v_codes"])
+    assert len(ops._vshadow) == 1 + sum(1 for v in ops._vshadow.values() if v[0]() is None)
