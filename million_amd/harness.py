@@ -16,10 +16,60 @@ lm_head, greedy argmax) is torch / hipBLASLt — plumbing, identical for every a
 from __future__ import annotations
 
 import math
+import time
 from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F
+
+
+class SectionTimers:
+    """The reference's --breakdown mode (scripts/utils/Timer.py:69-75, pq_utils.py:285-326, modeling_llama.py:403-443):
+    named wall-clock sections inside the attention forward, each closed by a device synchronise, accumulated over all
+    calls.  `with timers("sdpa"): ...`; timers.seconds -> {name: cumulative s}, timers.calls -> {name: count}."""
+
+    def __init__(self, sync=None):
+        self.seconds, self.calls = {}, {}
+        self._sync = sync or (torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None))
+
+    def __call__(self, name):
+        return _Section(self, name)
+
+    def reset(self):
+        self.seconds.clear()
+        self.calls.clear()
+
+
+class _Section:
+    def __init__(self, owner, name):
+        self.o, self.name = owner, name
+
+    def __enter__(self):
+        self.o._sync()
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        self.o._sync()
+        self.o.seconds[self.name] = self.o.seconds.get(self.name, 0.0) + time.perf_counter() - self.t0
+        self.o.calls[self.name] = self.o.calls.get(self.name, 0) + 1
+        return False
+
+
+class _NoTimers:
+    class _S:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *exc):
+            return False
+
+    _s = _S()
+
+    def __call__(self, name):
+        return self._s
+
+
+NO_TIMERS = _NoTimers()
 
 
 @dataclass
@@ -55,15 +105,31 @@ class HFBaselineCache:
     """fp16 full-KV cache grown by torch.cat (HF DynamicCache.update), + repeat_kv + SDPA."""
 
     def __init__(self, shape: LlamaShape, bs: int, ctx: int, device):
+        """ctx > 0: caches filled synthetically with ctx tokens; ctx = 0: empty, to be filled by prefill()."""
         self.G = shape.nh // shape.nh_k
         mk = lambda: torch.randn(bs, shape.nh_k, ctx, shape.d, device=device, dtype=torch.float16)
         self.k = [mk() for _ in range(shape.n_layers)]
         self.v = [mk() for _ in range(shape.n_layers)]
+        self.timers = NO_TIMERS
+
+    def prefill(self, layer, q, k, v):
+        """baseline_forward with q_len > 1 (modeling_llama.py:403-443): DynamicCache.update, repeat_kv, causal SDPA."""
+        with self.timers("cat"):
+            self.k[layer] = torch.cat([self.k[layer], k], dim=2)
+            self.v[layer] = torch.cat([self.v[layer], v], dim=2)
+        with self.timers("repeat_kv"):
+            kk, vv = repeat_kv(self.k[layer], self.G), repeat_kv(self.v[layer], self.G)
+        with self.timers("sdpa"):
+            return F.scaled_dot_product_attention(q, kk, vv, is_causal=True)
 
     def attend(self, layer, q, k, v):
-        self.k[layer] = torch.cat([self.k[layer], k], dim=2)
-        self.v[layer] = torch.cat([self.v[layer], v], dim=2)
-        return F.scaled_dot_product_attention(q, repeat_kv(self.k[layer], self.G), repeat_kv(self.v[layer], self.G))
+        with self.timers("cat"):
+            self.k[layer] = torch.cat([self.k[layer], k], dim=2)
+            self.v[layer] = torch.cat([self.v[layer], v], dim=2)
+        with self.timers("repeat_kv"):
+            kk, vv = repeat_kv(self.k[layer], self.G), repeat_kv(self.v[layer], self.G)
+        with self.timers("sdpa"):
+            return F.scaled_dot_product_attention(q, kk, vv)
 
 
 class StaticFP16Cache:
@@ -74,42 +140,57 @@ class StaticFP16Cache:
         mk = lambda: torch.randn(bs, shape.nh_k, ctx + max_new, shape.d, device=device, dtype=torch.float16)
         self.k = [mk() for _ in range(shape.n_layers)]
         self.v = [mk() for _ in range(shape.n_layers)]
+        self.timers = NO_TIMERS
 
     def attend(self, layer, q, k, v):
         s = self.shape
         T = self.T
-        self.k[layer][:, :, T:T + 1] = k
-        self.v[layer][:, :, T:T + 1] = v
+        with self.timers("copy"):
+            self.k[layer][:, :, T:T + 1] = k
+            self.v[layer][:, :, T:T + 1] = v
         bs = q.shape[0]
         qg = q.view(bs, s.nh_k, s.nh // s.nh_k, s.d)
-        out = F.scaled_dot_product_attention(qg, self.k[layer][:, :, :T + 1], self.v[layer][:, :, :T + 1])
+        with self.timers("sdpa"):
+            out = F.scaled_dot_product_attention(qg, self.k[layer][:, :, :T + 1], self.v[layer][:, :, :T + 1])
         if layer == s.n_layers - 1:
             self.T += 1
         return out.view(bs, s.nh, 1, s.d)
 
 
 class PQBackend:
-    def __init__(self, shape: LlamaShape, bs: int, ctx: int, max_new: int, device, M=64):
+    def __init__(self, shape: LlamaShape, bs: int, ctx: int, max_new: int, device, M=64, synthetic_fill=True):
+        """synthetic_fill: the code pages hold ctx random tokens (decode-only timing); otherwise the cache starts empty and
+        prefill() encodes a real prompt into it (attn_forward_custom_kernel's q_len > 1 branch, modeling_llama.py:540-543)."""
         from .pq_cache import PagedPQCache
         ps, cap = 64, 128
-        T0 = ctx // ps * ps
+        T0 = ctx // ps * ps if synthetic_fill else 0
         self.cache = PagedPQCache(bs=bs, nh=shape.nh, num_key_value_heads=shape.nh_k, M=M, layer_num=shape.n_layers,
-                                  d=shape.d, page_size=ps, extended_residual_size=cap, max_tokens=T0 + max_new + 2 * cap,
+                                  d=shape.d, page_size=ps, extended_residual_size=cap, max_tokens=ctx + max_new + 2 * cap,
                                   device=device)
         g = torch.Generator(device="cpu").manual_seed(5)
         self.cache.set_cent(torch.randn(M, 256, shape.d // M, generator=g).half().to(device),
                             torch.randn(M, 256, shape.d // M, generator=g).half().to(device))
-        gd = torch.Generator(device=device).manual_seed(11)
-        for pool in (self.cache.key_page_pool, self.cache.value_page_pool):
-            pool.copy_(torch.randint(0, 256, pool.shape, dtype=torch.uint8, device=device, generator=gd))
-        L = shape.n_layers
-        self.cache.set_host_state(([T0] * L, [0] * L, [T0] * L, [0] * L))      # window empty after prefill
-        for l in range(L):
-            self.cache._sync_lengths(l)
+        if synthetic_fill:
+            gd = torch.Generator(device=device).manual_seed(11)
+            for pool in (self.cache.key_page_pool, self.cache.value_page_pool):
+                pool.copy_(torch.randint(0, 256, pool.shape, dtype=torch.uint8, device=device, generator=gd))
+            L = shape.n_layers
+            self.cache.set_host_state(([T0] * L, [0] * L, [T0] * L, [0] * L))      # window empty after prefill (SURVEY 3.3)
+            for l in range(L):
+                self.cache._sync_lengths(l)
         self.use_dev_lengths = False
+        self.timers = NO_TIMERS
+
+    def prefill(self, layer, q, k, v):
+        with self.timers("prefill_encode+sdpa"):
+            return self.cache.prefill(q, k, v, layer)
 
     def attend(self, layer, q, k, v):
-        return self.cache.decoding_with_pages(q, k, v, layer, use_dev_lengths=self.use_dev_lengths)
+        if self.timers is not NO_TIMERS and self.cache.residualed_tokens[layer] >= self.cache.extended_residual_size:
+            with self.timers("flush_encode"):      # the flush that decoding_with_pages would do first (pq_utils.py:288-302)
+                self.cache.flush_to_pages(layer, use_dev_lengths=self.use_dev_lengths)
+        with self.timers("kernel"):                # window append + fused PQ attention (pq_utils.py:304-326): one launch
+            return self.cache.decoding_with_pages(q, k, v, layer, use_dev_lengths=self.use_dev_lengths)
 
 
 class LlamaShapeDecoder:
@@ -133,6 +214,7 @@ class LlamaShapeDecoder:
         self.lm_head = w(s.vocab, h)
         inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.d, 2, device=device, dtype=torch.float32) / s.d))
         self.inv_freq = inv
+        self.timers = NO_TIMERS
 
     def _rms(self, x, w):
         v = x.float()
@@ -146,23 +228,63 @@ class LlamaShapeDecoder:
         x1, x2 = x[..., : self.s.d // 2], x[..., self.s.d // 2:]
         return x * cos + torch.cat([-x2, x1], -1) * sin
 
+    def _rope_seq(self, x, pos0):
+        # x (bs, heads, n, d), positions pos0 .. pos0 + n - 1
+        n = x.shape[2]
+        ang = (pos0 + torch.arange(n, device=x.device)).float()[:, None] * self.inv_freq[None, :]      # (n, d/2)
+        cos = torch.cat([ang.cos(), ang.cos()], -1)[None, None].half()
+        sin = torch.cat([ang.sin(), ang.sin()], -1)[None, None].half()
+        x1, x2 = x[..., : self.s.d // 2], x[..., self.s.d // 2:]
+        return x * cos + torch.cat([-x2, x1], -1) * sin
+
     def step(self, tokens, pos, backend):
-        s = self.s
+        s, tm = self.s, self.timers
         bs = tokens.shape[0]
         x = self.embed[tokens]                                           # (bs, hidden)
         for l, L in enumerate(self.layers):
             hN = self._rms(x, L["n1"])
-            qkv = F.linear(hN, L["wqkv"])
-            q = qkv[:, : s.nh * s.d].view(bs, s.nh, 1, s.d)
-            k = qkv[:, s.nh * s.d: (s.nh + s.nh_k) * s.d].view(bs, s.nh_k, 1, s.d)
-            v = qkv[:, (s.nh + s.nh_k) * s.d:].view(bs, s.nh_k, 1, s.d)
-            q, k = self._rope(q, pos), self._rope(k, pos)
-            a = backend.attend(l, q.contiguous(), k.contiguous(), v.contiguous())
-            x = x + F.linear(a.reshape(bs, s.nh * s.d), L["wo"])
+            with tm("qkv_proj"):
+                qkv = F.linear(hN, L["wqkv"])
+                q = qkv[:, : s.nh * s.d].view(bs, s.nh, 1, s.d)
+                k = qkv[:, s.nh * s.d: (s.nh + s.nh_k) * s.d].view(bs, s.nh_k, 1, s.d)
+                v = qkv[:, (s.nh + s.nh_k) * s.d:].view(bs, s.nh_k, 1, s.d)
+            with tm("rotary"):
+                q, k = self._rope(q, pos).contiguous(), self._rope(k, pos).contiguous()
+                v = v.contiguous()
+            a = backend.attend(l, q, k, v)
+            with tm("o_proj"):
+                x = x + F.linear(a.reshape(bs, s.nh * s.d), L["wo"])
             hN = self._rms(x, L["n2"])
             gu = F.linear(hN, L["wgu"])
             x = x + F.linear(F.silu(gu[:, : s.inter]) * gu[:, s.inter:], L["wd"])
         self.last_logits = F.linear(self._rms(x, self.norm), self.lm_head)
+        return self.last_logits.argmax(-1)
+
+    def prefill(self, tokens, backend, chunk=8192):
+        """The prompt pass (q_len > 1): tokens (bs, n) -> first generated token (bs,).  Per layer the whole prompt goes
+        through backend.prefill (PQ: bulk encode into pages + causal SDPA on the fp16 prompt, pq_utils.py:222-260); the
+        MLP runs in row chunks to bound the (n, 2*inter) intermediate."""
+        s, tm = self.s, self.timers
+        bs, n = tokens.shape
+        x = self.embed[tokens]                                           # (bs, n, hidden)
+        for l, L in enumerate(self.layers):
+            hN = self._rms(x, L["n1"])
+            with tm("qkv_proj"):
+                qkv = F.linear(hN, L["wqkv"])
+                q = qkv[..., : s.nh * s.d].view(bs, n, s.nh, s.d).transpose(1, 2)
+                k = qkv[..., s.nh * s.d: (s.nh + s.nh_k) * s.d].view(bs, n, s.nh_k, s.d).transpose(1, 2)
+                v = qkv[..., (s.nh + s.nh_k) * s.d:].view(bs, n, s.nh_k, s.d).transpose(1, 2).contiguous()
+            with tm("rotary"):
+                q, k = self._rope_seq(q, 0).contiguous(), self._rope_seq(k, 0).contiguous()
+            a = backend.prefill(l, q, k, v)                              # (bs, nh, n, d)
+            with tm("o_proj"):
+                x = x + F.linear(a.transpose(1, 2).reshape(bs, n, s.nh * s.d), L["wo"])
+            del qkv, q, k, v, a
+            for c0 in range(0, n, chunk):
+                hN = self._rms(x[:, c0:c0 + chunk], L["n2"])
+                gu = F.linear(hN, L["wgu"])
+                x[:, c0:c0 + chunk] += F.linear(F.silu(gu[..., : s.inter]) * gu[..., s.inter:], L["wd"])
+        self.last_logits = F.linear(self._rms(x[:, -1], self.norm), self.lm_head)
         return self.last_logits.argmax(-1)
 
 

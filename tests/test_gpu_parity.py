@@ -929,3 +929,77 @@ def test_rowmajor_v_shadow_reuse_and_invalidation(env, oracle):
     del v2
     call(t["v_codes"])
     assert len(ops._vshadow) == 1 + sum(1 for v in ops._vshadow.values() if v[0]() is None)
+
+
+def test_harness_pq_step_attention_against_oracle(env, oracle):
+    """million_amd/harness.py, PQ backend: inside a real decode step of the Llama-shaped model (q/k/v projections and
+    RoPE in torch, then PagedPQCache.decoding_with_pages as attn_forward_custom_kernel calls it,
+    modeling_llama.py:455-554) the attention output of every layer equals the oracle's, evaluated on the cache's own
+    state (codes read back through the page table, window rows, the new K/V row); the prompt is really prefilled (bulk
+    encode into pages), the decode steps cross a window flush; eager launches and hipGraph replay."""
+    torch, ops = env
+    from million_amd import harness as H
+    shape = H.LlamaShape(hidden=256, n_layers=2, nh=16, nh_k=4, d=128, inter=512, vocab=500)
+    dev = torch.device("cuda", 0)
+    model = H.LlamaShapeDecoder(shape, dev, seed=3)
+    n_prompt, bs, nl = 700, 1, shape.n_layers
+    for mode in ("eager", "graph"):
+        be = H.PQBackend(shape, bs, n_prompt, 256, dev, synthetic_fill=False)
+        cache = be.cache
+        prompt = torch.randint(0, shape.vocab, (bs, n_prompt), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+        tokens = model.prefill(prompt, be).clone()
+        assert cache._T[0] == n_prompt and cache.residualed_tokens[0] == 0
+        pos = torch.full((bs,), n_prompt, dtype=torch.long, device=dev)
+        captured, orig = [], be.attend
+
+        def spy(layer, q, k, v):
+            out = orig(layer, q, k, v)
+            captured.append((layer, q.clone(), k.clone(), v.clone(), out))      # under capture the clones are graph nodes
+            return out
+        be.attend = spy
+        caps_of = None
+        if mode == "graph":      # ctor: one eager step, then the "plain" and the "flush" capture; a replay refreshes its clones
+            gd = H.GraphedPQDecoder(model, be, tokens, pos)
+            assert len(captured) == 3 * nl
+            caps_of = {"plain": captured[nl:2 * nl], "flush": captured[2 * nl:3 * nl]}
+        ck, cv = cache.key_cent.cpu().numpy(), cache.value_cent.cpu().numpy()
+        for step in range(140):                                 # the window fills after 128 steps: one flush inside
+            flush = cache.next_step_flushes()
+            T, r, rs = cache._T[0], cache.residualed_tokens[0], cache._rstart[0]      # what the launches of this step read
+            if flush:
+                T, r, rs = T + 64, r - 64, (rs + 64) % 128
+            check = step in (0, 1, 127, 128, 129, 139)
+            if check:
+                win = [(cache.key_residual_cache[l].cpu().numpy().copy(), cache.value_residual_cache[l].cpu().numpy().copy())
+                       for l in range(nl)]
+            captured.clear()
+            if mode == "graph":
+                gd.step()
+            else:
+                tokens.copy_(model.step(tokens, pos, be))
+                pos.add_(1)
+            torch.cuda.synchronize()
+            if not check:
+                continue
+            assert flush == (step == 128)
+            caps = caps_of["flush" if flush else "plain"] if mode == "graph" else list(captured)
+            assert len(caps) == nl
+            kpool, vpool = cache.key_page_pool.cpu().numpy(), cache.value_page_pool.cpu().numpy()
+            for (layer, q, k, v, out) in caps:
+                ids = cache.page_ids[layer].cpu().numpy()
+                n_pages = (T + 63) // 64
+                kc = np.concatenate([kpool[ids[:, :, p]] for p in range(n_pages)], axis=2)[:, :, :T]          # (bs, nh_k, T, M)
+                vc = np.concatenate([vpool[ids[:, :, p]].transpose(0, 1, 3, 2) for p in range(n_pages)], axis=2)[:, :, :T]
+                kw, vw = win[layer]
+                if flush:      # the 64 oldest window rows became codes: they must be the oracle's encode of those rows
+                    old = (np.arange(64) + (rs - 64) % 128) % 128
+                    np.testing.assert_array_equal(kc[:, :, T - 64:], oracle.pq_encode(kw[:, :, old], ck))
+                    np.testing.assert_array_equal(vc[:, :, T - 64:], oracle.pq_encode(vw[:, :, old], cv))
+                rows = (np.arange(r) + rs) % 128
+                kres = np.zeros((bs, shape.nh_k, 128, 128), np.float16)
+                vres = np.zeros((bs, shape.nh_k, 128, 128), np.float16)
+                kres[:, :, :r], vres[:, :, :r] = kw[:, :, rows], vw[:, :, rows]
+                kres[:, :, r], vres[:, :, r] = k.cpu().numpy()[:, :, 0], v.cpu().numpy()[:, :, 0]
+                gold = oracle.decode_attn(q.cpu().numpy(), kc, vc, ck, cv, kres, vres, r + 1)
+                _check(out.float().cpu().numpy(), gold, f"{mode} step {step} layer {layer}")
+        assert cache._T[0] == n_prompt + 64 and cache.residualed_tokens[0] == 140 - 64

@@ -171,6 +171,38 @@ def test_harness_fp16_backends_agree_cpu():
     assert r.shape == (2, 4, 3, 1) and torch.equal(r[:, 1], x[:, 0]) and torch.equal(r[:, 2], x[:, 1])
 
 
+def test_harness_prefill_equals_stepwise_and_timers_cpu():
+    """harness.LlamaShapeDecoder.prefill (the q_len > 1 pass that TTFT times, speedtest.py:105) gives the logits that
+    prefilling one token less and then decoding the last token gives; SectionTimers accumulates the reference's
+    breakdown sections (speedtest.py:110-117)."""
+    from million_amd import harness as H
+    shape = H.LlamaShape(hidden=64, n_layers=2, nh=4, nh_k=2, d=16, inter=96, vocab=50)
+    torch.manual_seed(1)
+    model = H.LlamaShapeDecoder(shape, torch.device("cpu"))
+    for L in model.layers:
+        for k in L:
+            L[k] = L[k].float()
+    model.embed, model.lm_head, model.norm = model.embed.float(), model.lm_head.float(), model.norm.float()
+
+    def empty():
+        be = H.HFBaselineCache(shape, 2, 0, torch.device("cpu"))
+        be.k, be.v = [t.float() for t in be.k], [t.float() for t in be.v]
+        return be
+    toks = torch.randint(0, 50, (2, 24))
+    model.prefill(toks, empty(), chunk=7)
+    full = model.last_logits.clone()
+    be = empty()
+    tm = H.SectionTimers(sync=lambda: None)
+    model.timers = be.timers = tm
+    model.prefill(toks[:, :23], be)
+    model.step(toks[:, 23], torch.full((2,), 23), be)
+    model.timers = H.NO_TIMERS
+    assert (full - model.last_logits).abs().max() < 1e-5
+    assert be.k[0].shape[2] == 24
+    assert set(tm.seconds) == {"qkv_proj", "rotary", "cat", "repeat_kv", "sdpa", "o_proj"}
+    assert tm.calls["sdpa"] == 2 * shape.n_layers and all(v >= 0 for v in tm.seconds.values())
+
+
 def test_fvecs_and_centroid_formats(tmp_path):
     """million_amd/formats.py against the byte layout the reference writes (fvecio.py:23-43; main_pq.py:222-260)."""
     import struct
