@@ -1132,10 +1132,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     typedef typename std::conditional<MS == 64, gptr_v4u, gptr_v2u>::type KPtr;      // global address space: no FLAT loads
     const unsigned k_lane_off = ((unsigned)c16 << kLog2M) + (unsigned)(MS / 4) * q4;    // row c16 (+16 for g2 = 1), quarter q4
     const unsigned v_lane_off = ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
-#define UNIT_REQ(SL, J)                                                                                            \
+#define UNIT_REQ_K(SL, J)                                                                                          \
     {                                                                                                              \
         const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
-        const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
         gptr_u8 kb_;                                                                                               \
         if (k_paged) {                                                                                             \
             const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
@@ -1149,10 +1148,16 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 ring[SL].k[g2] = *(KPtr)(kb_ + (((unsigned)min(tu_ + c16 + 16 * g2, T_ld - 1) << kLog2M) +         \
                                                 (unsigned)(MS / 4) * q4));                                         \
         }                                                                                                          \
+    }
+#define UNIT_REQ_V(SL, J)                                                                                          \
+    {                                                                                                              \
+        const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
+        const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
         const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + p.ps_shift)) + tin);                         \
         ring[SL].v[0] = *(gptr_v4u)(vb_ + v_lane_off);                                                             \
         if (MS == 64) ring[SL].v[MS == 64 ? 1 : 0] = *(gptr_v4u)(vb_ + v_lane_off + (32u << p.ps_shift));          \
     }
+#define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
     UNIT_REQ(0, 0)
     UNIT_REQ(1, 1)
     STAMP(7);
@@ -1218,20 +1223,20 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #define BLOCK(U4, J)                                                                                               \
     {                                                                                                              \
         v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
+        UNIT_REQ_K(U4, (J) + 4)      /* the K bytes of slot U4 (round J) were consumed by the previous block */    \
         _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                           \
             VS(i);                                                                                                 \
-            if (i + 1 < NV) VG(U4, i + 1);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            if (i + 1 < NV) VG(U4, i + 1); else VG(((U4) + 1) & 3, 0);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
             _Pragma("unroll") for (int k = 0; k < SPV; ++k) {                                                      \
                 KM(SPV * i + k);                                                                                   \
                 if (SPV * i + k + 2 < 8) KG(((U4) + 1) & 3, SPV * i + k + 2);                                      \
+                else KG(((U4) + 2) & 3, SPV * i + k + 2 - 8);                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
             }                                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                          \
-        VG(((U4) + 1) & 3, 0);                                                                                     \
-        KG(((U4) + 2) & 3, 0);                                                                                     \
-        KG(((U4) + 2) & 3, 1);                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        UNIT_REQ(U4, (J) + 4)                                                                                      \
+        UNIT_REQ_V(U4, (J) + 4)                                                                                    \
         SCORES_OUT((J) + 1)                                                                                        \
         softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
         value_prep(sc, P);                                                                                         \
@@ -1334,6 +1339,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef BLOCK
 #undef VALUE_ALONE
 #undef UNIT_REQ
+#undef UNIT_REQ_K
+#undef UNIT_REQ_V
     STAMP(3);
     merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
 #undef STAMP
