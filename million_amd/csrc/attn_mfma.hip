@@ -1358,9 +1358,11 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
     return hipGetLastError() == hipSuccess ? MILLION_OK : MILLION_ERR_LAUNCH;
 }
 
-// rcap <= kNW * kResRows: every window row of a split has a slot in some wave's residual tile
+// A split takes every nsplit-th window row and has kNW * kResRows = 128 slots for them in its waves' residual tiles:
+// windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
+// flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 bool attn_mfma_shape_ok(const AttnParams &p) {
-    return p.d == 128 && (p.M == 64 || p.M == 32) && p.C == 256 && p.G <= kMaxG && p.rcap <= kNW * kResRows;
+    return p.d == 128 && (p.M == 64 || p.M == 32) && p.C == 256 && p.G <= kMaxG && p.rcap <= 4 * kNW * kResRows;
 }
 
 bool attn_mfma_supported(const AttnParams &p) {
@@ -1384,6 +1386,8 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     // the kernels deal whole 32-token units to the splits (first units % ns splits carry one more): len = the longest
     const int units = p.T > 0 ? (p.T + 31) / 32 : 1;
     if (ns > units) ns = units;
+    const int ns_window = (p.rcap + kNW * kResRows - 1) / (kNW * kResRows);      // splits the residual window needs
+    if (ns < ns_window) ns = ns_window;      // (a split beyond the last unit just has no code units)
     int len = 32 * ((units + ns - 1) / ns);
     p.nsplit = ns;
     p.nslots = ns;

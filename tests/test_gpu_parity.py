@@ -1003,3 +1003,37 @@ def test_harness_pq_step_attention_against_oracle(env, oracle):
                 gold = oracle.decode_attn(q.cpu().numpy(), kc, vc, ck, cv, kres, vres, r + 1)
                 _check(out.float().cpu().numpy(), gold, f"{mode} step {step} layer {layer}")
         assert cache._T[0] == n_prompt + 64 and cache.residualed_tokens[0] == 140 - 64
+
+
+@pytest.mark.parametrize("T,r,start,M", [(0, 256, 0, 64), (40, 200, 100, 64), (5000, 256, 255, 64), (33000, 129, 7, 32)])
+def test_attn_window_of_256_rows_on_mfma(T, r, start, M, env, oracle):
+    """extended_residual_size = 256 (the reference's flash_decoding_paged_v_*_Lt256 names; PagedPQCache's advertised
+    extended_residual in {64, 128, 256}): windows longer than 128 rows stay on the MFMA kernels - the launch uses at
+    least two splits, each takes every nsplit-th row into its 128 tile slots."""
+    torch, ops = env
+    from million_amd import _lib
+    nh, nhk, ps, cap = 32, 8, 64, 256
+    c = synth.attn_case(9300 + T % 71 + r, 1, nh, nhk, 128, M, 256, T, r, Lt=cap)
+    gold = oracle.decode_attn(**c)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda() if T else torch.zeros(1, nhk, 1, dtype=torch.int32, device="cuda")
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda(), kp, vp, kr, vr, r,
+                             M=M, C=256, n_tokens=T, resid_start=start, k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), gold, f"cap 256 T={T} r={r}")
+    desc = ops.make_attn_desc(t["q"], kr, nh_k=nhk, M=M, C=256, n_tokens=max(T, 1), r=r, k_paged=True, v_paged=True,
+                              page_size=ps, n_pages_cap=max(ids_t.shape[2], 1))
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
+    if T and M == 64:      # the 13-argument name with Lt256 (paged_pq_utils.py:547), row-major K + paged V, int64 ids
+        import bindings
+        fn = getattr(bindings, "flash_decoding_paged_v_f16u8_Ns32Lt256d128M64C256")
+        po = torch.empty(1, nh, 33, 128, dtype=torch.float16, device="cuda")
+        pl = torch.empty(1, nh, 33, dtype=torch.float16, device="cuda")
+        out2 = fn(t["q"], t["k_codes"], t["k_cents"], t["k_res"][:, :, :r], torch.from_numpy(ids).cuda(),
+                  torch.from_numpy(vpool).cuda(), t["v_cents"], t["v_res"][:, :, :r], r, ids.shape[2], ps, po, pl)
+        _check(out2.cpu().numpy(), gold, "bindings Lt256")
