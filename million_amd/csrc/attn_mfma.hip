@@ -1009,12 +1009,23 @@ template <int MS> struct StreamTypes;
 template <> struct StreamTypes<64> { typedef UnitCodes Unit; typedef unsigned E[8]; };
 template <> struct StreamTypes<32> { typedef UnitCodes32 Unit; typedef unsigned E[2][8]; };
 
-// the K gathers of score stage st (0..7) of a unit
+// the K gathers of score stage st (0..7) of a unit; CL2 = log2 of the centroids per subspace (8: C = 256, 7: C = 128):
+// a subspace's row of the K row image is (4 << CL2) bytes at M = 64 and (8 << CL2) at M = 32, a stage covers 16 << CL2
+template <int CL2>
 __device__ __forceinline__ void st_kgather(const UnitCodes &u, int st, unsigned kbase, unsigned (&a)[4]) {
-    k_gather(u.k[st >> 2][st & 3], kbase + (st & 3) * 4096, a);
+    const unsigned w = u.k[st >> 2][st & 3], base = kbase + (st & 3) * (16u << CL2);
+    a[0] = lds32(base + 0 * (4u << CL2) + ((w & 0xffu) << 2));
+    a[1] = lds32(base + 1 * (4u << CL2) + (((w >> 8) & 0xffu) << 2));
+    a[2] = lds32(base + 2 * (4u << CL2) + (((w >> 16) & 0xffu) << 2));
+    a[3] = lds32(base + 3 * (4u << CL2) + ((w >> 24) << 2));
 }
+template <int CL2>
 __device__ __forceinline__ void st_kgather(const UnitCodes32 &u, int st, unsigned kbase, unsigned (&a)[4]) {
-    k_gather32(u.k[st >> 2][(st & 3) >> 1], st & 3, kbase + (st & 3) * 4096, a);
+    const unsigned w = u.k[st >> 2][(st & 3) >> 1], base = kbase + (st & 3) * (16u << CL2);
+    const unsigned sh = 16 * (st & 1);
+    const v2u lo = lds64(base + 0 * (8u << CL2) + (((w >> sh) & 0xffu) << 3));
+    const v2u hi = lds64(base + 1 * (8u << CL2) + (((w >> (sh + 8)) & 0xffu) << 3));
+    a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
 }
 // the V gathers of value step i (M = 64: 4 steps of 8 four-byte gathers; M = 32: 2 steps of 8 eight-byte gathers)
 __device__ __forceinline__ void st_vgather(const UnitCodes &u, int i, unsigned vconst0, unsigned vconst1, unsigned (&e)[8]) {
@@ -1039,13 +1050,14 @@ __device__ __forceinline__ void st_vstep(const unsigned (&e)[2][8], const unsign
     v_step(e[1], Ps, O[1]);      // dims 4m + 2, 3
 }
 
-template <int MS, int MODE>
+template <int MS, int MODE, int CL2 = 8>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) {
     typedef typename StreamTypes<MS>::Unit Unit;
     typedef typename StreamTypes<MS>::E EBuf;
     constexpr int kLog2M = MS == 64 ? 6 : 5;
     constexpr int NV = MS == 64 ? 4 : 2;       // value steps per unit (16 tokens each for M = 64 subspaces in two halves)
     constexpr int SPV = 8 / NV;                // score stages that ride along with one value step
+    constexpr int NT = 8 >> (8 - CL2);         // 16-byte pieces of a codebook image per thread (C = 256: 64 KiB, C = 128: 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1100,12 +1112,12 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     // the K codebook goes out before anything that depends on a length or a page id (the CU's load path takes ~28 cycles
     // per 1-KiB wave request, in order: what is requested first is there first)
-    v4u tabk[8], tabv[8];
+    v4u tabk[NT], tabv[NT];
     const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
     {
         const v4u *ks = (const v4u *)p.k_tab;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) tabk[i] = ks[((i + rot) & 7) * (kNW * 64) + tid];
+        for (int i = 0; i < NT; ++i) tabk[i] = ks[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
     }
     if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4); only the masks and the window depend on it
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
@@ -1164,7 +1176,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     {
         v4u *ld = (v4u *)smem;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ld[((i + rot) & 7) * (kNW * 64) + tid] = tabk[i];
+        for (int i = 0; i < NT; ++i) ld[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabk[i];
     }
     STAMP(8);
     __syncthreads();
@@ -1193,14 +1205,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     STAMP(2);
 
-    const unsigned kbase = (unsigned)q4 * 16u * 1024u;
+    const unsigned kbase = (unsigned)q4 * (64u << CL2);      // quarter q4 of the K row image: its 16 (M = 64) / 8 (M = 32) subspaces
     const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3));
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);      // M = 64 only
 
     unsigned a[2][4], P[2][4];
     EBuf e[2];
     float sc[8];
-#define KG(SL, ST) st_kgather(ring[SL], ST, kbase, a[(ST) & 1])
+#define KG(SL, ST) st_kgather<CL2>(ring[SL], ST, kbase, a[(ST) & 1])
 #define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
         as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
 #define VG(SL, I) st_vgather(ring[SL], I, vconst0, vconst1, e[(I) & 1])
@@ -1276,9 +1288,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             for (int st = 0; st < 8; ++st) {
                 // the codebook requests first: its LDS store waits for everything requested before it, and
                 // must not wait for HBM-bound code bytes
-                if (st < 4) {
-                    tabv[2 * st] = vs[((2 * st + rot) & 7) * (kNW * 64) + tid];
-                    tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & 7) * (kNW * 64) + tid];
+                if (2 * st < NT) {
+                    tabv[2 * st] = vs[((2 * st + rot) & (NT - 1)) * (kNW * 64) + tid];
+                    tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & (NT - 1)) * (kNW * 64) + tid];
                 }
                 KM(st);
                 if (st + 2 < 8) KG(0, st + 2);
@@ -1297,7 +1309,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         {
             v4u *ldv = (v4u *)(smem + kVBase);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ldv[((i + rot) & 7) * (kNW * 64) + tid] = tabv[i];
+            for (int i = 0; i < NT; ++i) ldv[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabv[i];
         }
         STAMP(12);
         __syncthreads();
@@ -1362,7 +1374,7 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 bool attn_mfma_shape_ok(const AttnParams &p) {
-    return p.d == 128 && (p.M == 64 || p.M == 32) && p.C == 256 && p.G <= kMaxG && p.rcap <= 4 * kNW * kResRows;
+    return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxG && p.rcap <= 4 * kNW * kResRows;
 }
 
 bool attn_mfma_supported(const AttnParams &p) {
@@ -1403,12 +1415,18 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     // streaming kernel: rounds per wave = ceil(T / (ns * 256 tokens)) must fit the 64 page ids a wave preloads
     const bool stream_ok = p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64;
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
     const dim3 grid(ns, bh), block(kNW * 64);
-    if (g_mfma_policy == 0 && stream_ok) {
+    if (p.C == 128) {      // 128 centroids per subspace (reference setup.py:15): streaming kernel by run-time layout flags only
+        if (!stream_ok) return kAttnNotHandled;      // T = 0 or more than 64 rounds per wave: the caller takes the generic kernel
+        if (p.M == 64) hipLaunchKernelGGL((attn_stream_kernel<64, 2, 7>), grid, block, kLdsBytes, s, p);
+        else hipLaunchKernelGGL((attn_stream_kernel<32, 2, 7>), grid, block, kLdsBytes, s, p);
+    } else if (g_mfma_policy == 0 && stream_ok) {
         if (p.M == 64) {
             if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<64, 0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<64, 1>), grid, block, kLdsBytes, s, p);

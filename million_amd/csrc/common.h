@@ -314,6 +314,7 @@ struct EncParams {
 
 // host-side launchers (defined in the .hip files)
 int launch_attn_generic(const AttnParams &p, hipStream_t s);
+constexpr int kAttnNotHandled = 1;      // launch_attn_mfma: shape fine in principle, this call is for the generic kernel
 int launch_attn_mfma(const AttnParams &p, hipStream_t s);
 int launch_encode(const EncParams &p, hipStream_t s);
 int launch_decode(const void *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s);

@@ -364,8 +364,10 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.ws_cnt2 = p.ws_cnt + p.bs * p.nh_k;
     p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
-    if (!g_force_generic && attn_mfma_supported(p)) return launch_attn_mfma(p, (hipStream_t)stream);
-    if (!g_force_generic && attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) {
+    if (!g_force_generic && attn_mfma_supported(p)) {
+        const int rc_fast = launch_attn_mfma(p, (hipStream_t)stream);
+        if (rc_fast != kAttnNotHandled) return rc_fast;
+    } else if (!g_force_generic && attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) {
         // reference 10-arg layout on the MFMA shapes: transpose V into scratch pages, then the fast kernel
         uint8_t *scratch = (uint8_t *)workspace + attn_partial_bytes(p.bs, p.nh_k, p.G, p.d);
         const int n_pages = (p.T + 63) / 64;
@@ -373,8 +375,10 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
                            p.v_codes, scratch, p.nh_k, p.T, p.M, p.v_sb, p.v_sh, n_pages);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
-        p.v_codes = scratch; p.v_paged = 1; p.v_identity = 1; p.page_size = 64; p.ps_shift = 6; p.n_pages_cap = n_pages;
-        return launch_attn_mfma(p, (hipStream_t)stream);
+        AttnParams pt = p;
+        pt.v_codes = scratch; pt.v_paged = 1; pt.v_identity = 1; pt.page_size = 64; pt.ps_shift = 6; pt.n_pages_cap = n_pages;
+        const int rc_fast = launch_attn_mfma(pt, (hipStream_t)stream);
+        if (rc_fast != kAttnNotHandled) return rc_fast;
     }
     choose_splits(p, 256);
     p.nslots = p.nsplit + 1;

@@ -310,8 +310,8 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
     else:
         _check_rowmajor("value_codes", v_codes, M, n_tokens)
     v_dense = False
-    if (not v_paged and not k_paged and n_tokens > 0 and C == 256 and q.shape[3] == 128 and M in (32, 64)
-            and k_res.shape[2] <= 128 and q.shape[1] // nh_k <= 8 and dev_lengths is None):
+    if (not v_paged and not k_paged and n_tokens > 0 and C in (128, 256) and q.shape[3] == 128 and M in (32, 64)
+            and k_res.shape[2] <= 512 and q.shape[1] // nh_k <= 8 and dev_lengths is None):
         # the reference's 10-argument layout on the fast shapes: transposed pages of V, made once per code tensor
         v_codes = _v_pages_of(v_codes, n_tokens)
         v_paged, v_dense, page_size, n_pages_cap = True, True, 64, (n_tokens + 63) // 64

@@ -1037,3 +1037,23 @@ def test_attn_window_of_256_rows_on_mfma(T, r, start, M, env, oracle):
         out2 = fn(t["q"], t["k_codes"], t["k_cents"], t["k_res"][:, :, :r], torch.from_numpy(ids).cuda(),
                   torch.from_numpy(vpool).cuda(), t["v_cents"], t["v_res"][:, :, :r], r, ids.shape[2], ps, po, pl)
         _check(out2.cpu().numpy(), gold, "bindings Lt256")
+
+
+@pytest.mark.parametrize("M,T,r,bs", [(64, 5000, 17, 1), (32, 40000, 128, 1), (64, 33000, 64, 2), (64, 0, 40, 1), (32, 100, 1, 1)])
+def test_attn_c128_on_mfma(M, T, r, bs, env, oracle):
+    """C = 128 centroids per subspace (nbits 7; the reference compiles C in {128, 256}, setup.py:15) on the streaming MFMA
+    kernel: codebook images of half the size, same code layout; T = 0 falls back to the generic kernel."""
+    torch, ops = env
+    from million_amd import _lib
+    nh, nhk = 32, 8
+    c = synth.attn_case(9500 + T % 61 + M, bs, nh, nhk, 128, M, 128, T, r)
+    assert c["k_codes"].max(initial=0) < 128
+    gold = oracle.decode_attn(**c)
+    _check(_run_rowmajor(torch, ops, c, M, 128), gold, "C=128 rowmajor")
+    if T:
+        _check(_run_paged(torch, ops, oracle, c, M, 128, 64), gold, "C=128 paged")
+        _check(_run_paged(torch, ops, oracle, c, M, 128, 128, k_paged=False, i64=True), gold, "C=128 mixed ps=128")
+        t = _dev(torch, c)
+        desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=128, n_tokens=T, r=r, k_paged=True, v_paged=True,
+                                  page_size=64, n_pages_cap=(T + 63) // 64)
+        assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
