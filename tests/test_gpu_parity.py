@@ -1057,3 +1057,37 @@ def test_attn_c128_on_mfma(M, T, r, bs, env, oracle):
         desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=128, n_tokens=T, r=r, k_paged=True, v_paged=True,
                                   page_size=64, n_pages_cap=(T + 63) // 64)
         assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
+
+
+@pytest.mark.parametrize("policy", [0, 2, 1], ids=["stream", "grouped", "generic"])
+def test_device_lengths_are_clamped_not_trusted(policy, env, oracle):
+    """Device-resident lengths outside their ranges (T above the host bound, r above the window, ring start past the
+    capacity, negative values) must become a shorter context / window, never an out-of-bounds read: the kernels clamp
+    T to [0, host bound], r to [0, cap] (cap - 1 with a fused append) and an out-of-range start to 0."""
+    torch, ops = env
+    bs, nh, nhk, ps, cap, T = 4, 8, 2, 64, 128, 1500
+    c = synth.attn_case(9700, bs, nh, nhk, 128, 64, 256, T, cap)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    bad = [[T + 100000, cap + 77, 0, 0], [-5, -3, 0, 0], [700, 40, cap + 9, 0], [T, 20, -1, 0]]
+    eff = [(T, cap, 0), (0, 0, 0), (700, 40, 0), (T, 20, 0)]        # what the clamps make of them
+    lengths = torch.tensor(bad, dtype=torch.int32, device="cuda")
+    ops.set_force_generic(policy)
+    try:
+        out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda(), kp, vp, t["k_res"],
+                                 t["v_res"], 0, M=64, C=256, n_tokens=T, k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps,
+                                 dev_lengths=lengths)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_force_generic(0)
+    o = out.cpu().numpy()
+    for b, (Tb, rb, sb) in enumerate(eff):
+        cb = {k: (v[b:b + 1] if isinstance(v, np.ndarray) and v.shape[0] == bs else v) for k, v in c.items()}
+        cb["k_codes"], cb["v_codes"], cb["r"] = cb["k_codes"][:, :, :Tb], cb["v_codes"][:, :, :Tb], rb
+        if Tb == 0 and rb == 0:
+            assert np.array_equal(o[b], np.zeros_like(o[b]))
+        else:
+            _check(o[b:b + 1], oracle.decode_attn(**cb), f"batch item {b}: lengths {bad[b]} -> {eff[b]}")
