@@ -18,6 +18,9 @@ ap.add_argument("--layers", type=int, default=32)
 ap.add_argument("--shuffle-pages", action="store_true", help="random page permutation (default: ids in allocation order, as PagedPQCache hands them out)")
 ap.add_argument("--iters", type=int, default=96)
 ap.add_argument("--dev-lengths", action="store_true")
+ap.add_argument("--bindings-10arg", action="store_true",
+                help="time the reference's 10-argument call (bindings.flash_decoding_allocated_buffer_*: row-major K and V "
+                     "codes, the same tensors on every call of a layer) instead of the paged call")
 ap.add_argument("--zero-codes", action="store_true", help="diagnostic: all code bytes 0 (every LDS gather is a broadcast: no bank conflicts)")
 ap.add_argument("--same-page", action="store_true", help="diagnostic: every page id = 0 (codes come from L2, not HBM)")
 args = ap.parse_args()
@@ -46,7 +49,19 @@ for cfg in args.cfg:
     vr = torch.randn(bs, nhk, 128, d, device=dev).half()
     dl = torch.tensor([[T, r, 0, 0]] * bs, dtype=torch.int32, device=dev) if args.dev_lengths else None
 
+    if args.bindings_10arg:
+        import bindings
+        fn = getattr(bindings, f"flash_decoding_allocated_buffer_f16u8_Ns32Lt128d128M{M}C{C}")
+        kcent, vcent = torch.randn(M, C, d // M, device=dev).half(), torch.randn(M, C, d // M, device=dev).half()
+        rm = [(torch.randint(0, 256, (bs, nhk, T, M), dtype=torch.uint8, device=dev),
+               torch.randint(0, 256, (bs, nhk, T, M), dtype=torch.uint8, device=dev)) for _ in range(len(states))]
+        po = torch.empty(bs, nh, 33, d, dtype=torch.float16, device=dev)
+        pl = torch.empty(bs, nh, 33, dtype=torch.float16, device=dev)
+
     def run(l):
+        if args.bindings_10arg:
+            kcod, vcod = rm[l % len(rm)]
+            return fn(q, kcod, vcod, kcent, vcent, kr, vr, r, po, pl)
         kp, vp, ids = states[l % len(states)]
         return ops.pq_decode_attn(q, kp, vp, kc, vc, kr, vr, r, M=M, C=C, n_tokens=T, k_page_ids=ids, v_page_ids=ids,
                                   page_size=ps, dev_lengths=dl)
@@ -70,6 +85,8 @@ for cfg in args.cfg:
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / args.iters)
     alg = 2 * bs * nhk * T * M + 2 * bs * nhk * r * d * 2 + 2 * M * C * (d // M) * 2 + bs * nh * d * 4
+    if args.bindings_10arg:
+        tag = tag + " 10-arg"
     print(f"{tag:34s} bs={bs} T={T:6d} M={M}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs grouped {err:.1e}", flush=True)
     del states
     torch.cuda.empty_cache()
