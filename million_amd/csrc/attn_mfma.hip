@@ -82,39 +82,6 @@ __device__ __forceinline__ void stamp_lds_clear(bool on, int lane, int wave) {
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 
-// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row swaps:
-// pure VALU.  (ds_bpermute-based __shfl_xor goes through the LDS queue, which the code-byte gathers of the
-// other waves keep saturated: a dependent shuffle then costs a microsecond.)
-// NOTE (hipcc, ROCm 7.2): `__builtin_bit_cast(float, v[1])` on an element of an ext_vector (here the pair a
-// permlane swap builtin returns) is mis-lowered to element 0 — seen in the ISA: the row maximum became
-// "row 0" and the row sum 4 x row 0.  The elements are therefore copied to scalars and converted with
-// __uint_as_float.  tests: test_rows_reduce_selfcheck.
-__device__ __forceinline__ unsigned opaque_copy(unsigned x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-__device__ __forceinline__ v2u swap16_self(unsigned x) {      // rows {0,0,2,2} of x / rows {1,1,3,3} of x
-    return __builtin_amdgcn_permlane16_swap(x, opaque_copy(x), false, false);
-}
-__device__ __forceinline__ v2u swap32_self(unsigned x) {      // lower half twice / upper half twice
-    return __builtin_amdgcn_permlane32_swap(x, opaque_copy(x), false, false);
-}
-__device__ __forceinline__ float rows_max(float x) {
-    const v2u a = swap16_self(__float_as_uint(x));
-    const unsigned a0 = a[0], a1 = a[1];
-    const float m1 = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
-    const v2u b = swap32_self(__float_as_uint(m1));
-    const unsigned b0 = b[0], b1 = b[1];
-    return fmaxf(__uint_as_float(b0), __uint_as_float(b1));
-}
-__device__ __forceinline__ float rows_sum(float x) {
-    const v2u a = swap16_self(__float_as_uint(x));
-    const unsigned a0 = a[0], a1 = a[1];
-    const float s1 = __uint_as_float(a0) + __uint_as_float(a1);
-    const v2u b = swap32_self(__float_as_uint(s1));
-    const unsigned b0 = b[0], b1 = b[1];
-    return __uint_as_float(b0) + __uint_as_float(b1);
-}
 __device__ __forceinline__ float lane_bcast(float x, int lane_const) {       // v_readlane -> SGPR operand
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane_const));
 }

@@ -63,6 +63,41 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row swaps:
+// pure VALU.  (ds_bpermute-based __shfl_xor goes through the LDS queue, which the code-byte gathers of the
+// other waves keep saturated: a dependent shuffle then costs a microsecond.)
+// NOTE (hipcc, ROCm 7.2): `__builtin_bit_cast(float, v[1])` on an element of an ext_vector (here the pair a
+// permlane swap builtin returns) is mis-lowered to element 0 — seen in the ISA: the row maximum became
+// "row 0" and the row sum 4 x row 0.  The elements are therefore copied to scalars and converted with
+// __uint_as_float.  tests: test_rows_reduce_selfcheck.
+__device__ __forceinline__ unsigned opaque_copy(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ v2u swap16_self(unsigned x) {      // rows {0,0,2,2} of x / rows {1,1,3,3} of x
+    return __builtin_amdgcn_permlane16_swap(x, opaque_copy(x), false, false);
+}
+__device__ __forceinline__ v2u swap32_self(unsigned x) {      // lower half twice / upper half twice
+    return __builtin_amdgcn_permlane32_swap(x, opaque_copy(x), false, false);
+}
+__device__ __forceinline__ float rows_max(float x) {
+    const v2u a = swap16_self(__float_as_uint(x));
+    const unsigned a0 = a[0], a1 = a[1];
+    const float m1 = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+    const v2u b = swap32_self(__float_as_uint(m1));
+    const unsigned b0 = b[0], b1 = b[1];
+    return fmaxf(__uint_as_float(b0), __uint_as_float(b1));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    const v2u a = swap16_self(__float_as_uint(x));
+    const unsigned a0 = a[0], a1 = a[1];
+    const float s1 = __uint_as_float(a0) + __uint_as_float(a1);
+    const v2u b = swap32_self(__float_as_uint(s1));
+    const unsigned b0 = b[0], b1 = b[1];
+    return __uint_as_float(b0) + __uint_as_float(b1);
+}
 // Device-resident lengths are not trusted: T is clamped to the host bound the grid was sized for, r to the window
 // capacity (minus the row a fused append is about to add), the ring start to [0, cap).  Out-of-range values become a
 // shorter context / window, never an out-of-bounds read.
@@ -316,6 +351,9 @@ struct EncParams {
 int launch_attn_generic(const AttnParams &p, hipStream_t s);
 constexpr int kAttnNotHandled = 1;      // launch_attn_mfma: shape fine in principle, this call is for the generic kernel
 int launch_attn_mfma(const AttnParams &p, hipStream_t s);
+int launch_attn_tile(const AttnParams &p, hipStream_t s);
+bool attn_tile_supported(const AttnParams &p);   // shape taken by the tile kernel and V already in transposed pages
+bool attn_tile_shape_ok(const AttnParams &p);    // shape taken by the tile kernel once V is transposed
 int launch_encode(const EncParams &p, hipStream_t s);
 int launch_decode(const void *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s);
 int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, hipStream_t s);

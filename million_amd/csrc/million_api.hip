@@ -167,6 +167,7 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     if (p.k_paged || p.v_paged) {
         if (p.page_size != 32 && p.page_size != 64 && p.page_size != 128) { set_error("attn: page_size=%d (32, 64, 128)", p.page_size); return MILLION_ERR_SHAPE; }
         if ((long long)p.n_pages_cap * p.page_size < p.T) { set_error("attn: n_pages_cap*page_size < n_tokens"); return MILLION_ERR_ARG; }
+        if (p.n_pages_cap < 0 || (long long)p.bs * p.nh_k * p.n_pages_cap > 0x7fffffffLL) { set_error("attn: page table of %lld entries", (long long)p.bs * p.nh_k * p.n_pages_cap); return MILLION_ERR_ARG; }
     }
     p.dev_lengths = desc->dev_lengths;
     p.scale_log2e = 1.4426950408889634f / sqrtf((float)p.d);
@@ -321,7 +322,10 @@ int million_attn_kernel_kind(const million_attn_desc *desc) {
     if (fill_attn_params(desc, p) != MILLION_OK) return -1;
     if (g_force_generic) return 0;
     if (attn_mfma_supported(p)) return 1;
-    return (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) ? 2 : 0;   // 2 = transpose + MFMA
+    if (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) return 2;      // transpose + MFMA kernel
+    if (attn_tile_supported(p)) return 3;                                             // tile kernel
+    if (attn_tile_shape_ok(p) && !p.v_paged && !p.k_paged) return 4;                  // transpose + tile kernel
+    return 0;
 }
 
 static int attn_impl(const million_attn_desc *desc, const void *q, const void *k_new, const void *v_new,
@@ -364,21 +368,33 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.ws_cnt2 = p.ws_cnt + p.bs * p.nh_k;
     p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
-    if (!g_force_generic && attn_mfma_supported(p)) {
-        const int rc_fast = launch_attn_mfma(p, (hipStream_t)stream);
-        if (rc_fast != kAttnNotHandled) return rc_fast;
-    } else if (!g_force_generic && attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) {
-        // reference 10-arg layout on the MFMA shapes: transpose V into scratch pages, then the fast kernel
-        uint8_t *scratch = (uint8_t *)workspace + attn_partial_bytes(p.bs, p.nh_k, p.G, p.d);
-        const int n_pages = (p.T + 63) / 64;
-        hipLaunchKernelGGL(codes_transpose_kernel, dim3(n_pages, p.bs * p.nh_k), dim3(256), 0, (hipStream_t)stream,
-                           p.v_codes, scratch, p.nh_k, p.T, p.M, p.v_sb, p.v_sh, n_pages);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
-        AttnParams pt = p;
-        pt.v_codes = scratch; pt.v_paged = 1; pt.v_identity = 1; pt.page_size = 64; pt.ps_shift = 6; pt.n_pages_cap = n_pages;
-        const int rc_fast = launch_attn_mfma(pt, (hipStream_t)stream);
-        if (rc_fast != kAttnNotHandled) return rc_fast;
+    if (!g_force_generic) {
+        // 1. the streaming / grouped MFMA kernels (d = 128, M in {64, 32}); 2. the tile kernel (every other shape of
+        // the binding surface); both want V in transposed pages: the reference's 10-arg row-major layout is
+        // transposed into scratch pages first
+        if (attn_mfma_supported(p)) {
+            const int rc_fast = launch_attn_mfma(p, (hipStream_t)stream);
+            if (rc_fast != kAttnNotHandled) return rc_fast;
+        }
+        if (attn_tile_supported(p)) return launch_attn_tile(p, (hipStream_t)stream);
+        if (!p.v_paged && !p.k_paged && (attn_mfma_shape_ok(p) || attn_tile_shape_ok(p))) {
+            AttnParams pt = p;
+            pt.v_paged = 1; pt.v_identity = 1; pt.page_size = 64; pt.ps_shift = 6;
+            pt.n_pages_cap = p.T > 0 ? (p.T + 63) / 64 : 1;
+            if (p.T > 0) {
+                uint8_t *scratch = (uint8_t *)workspace + attn_partial_bytes(p.bs, p.nh_k, p.G, p.d);
+                hipLaunchKernelGGL(codes_transpose_kernel, dim3(pt.n_pages_cap, p.bs * p.nh_k), dim3(256), 0, (hipStream_t)stream,
+                                   p.v_codes, scratch, p.nh_k, p.T, p.M, p.v_sb, p.v_sh, pt.n_pages_cap);
+                const hipError_t e = hipGetLastError();
+                if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+                pt.v_codes = scratch;
+            }
+            if (p.T > 0 && attn_mfma_shape_ok(p)) {
+                const int rc_fast = launch_attn_mfma(pt, (hipStream_t)stream);
+                if (rc_fast != kAttnNotHandled) return rc_fast;
+            }
+            if (attn_tile_supported(pt)) return launch_attn_tile(pt, (hipStream_t)stream);
+        }
     }
     choose_splits(p, 256);
     p.nslots = p.nsplit + 1;

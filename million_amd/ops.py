@@ -310,9 +310,10 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
     else:
         _check_rowmajor("value_codes", v_codes, M, n_tokens)
     v_dense = False
-    if (not v_paged and not k_paged and n_tokens > 0 and C in (128, 256) and q.shape[3] == 128 and M in (32, 64)
-            and k_res.shape[2] <= 512 and q.shape[1] // nh_k <= 8 and dev_lengths is None):
-        # the reference's 10-argument layout on the fast shapes: transposed pages of V, made once per code tensor
+    if (not v_paged and not k_paged and n_tokens > 0 and C in (128, 256) and q.shape[3] in (64, 128) and M in (16, 32, 64)
+            and q.shape[1] // nh_k <= 8 and dev_lengths is None):
+        # the reference's 10-argument layout on the MFMA shapes (streaming and tile kernels: the whole binding surface):
+        # transposed pages of V, made once per code tensor
         v_codes = _v_pages_of(v_codes, n_tokens)
         v_paged, v_dense, page_size, n_pages_cap = True, True, 64, (n_tokens + 63) // 64
     desc = make_attn_desc(q, k_res, nh_k=nh_k, M=M, C=C, n_tokens=n_tokens, r=r, resid_start=resid_start,
@@ -367,8 +368,8 @@ def lengths_advance(dev_lengths: torch.Tensor, n_flushed: int, resid_cap: int) -
 
 
 def set_force_generic(on) -> None:
-    """0 / False = auto, 1 / True = generic kernel only, 2 = grouped MFMA kernel only, 3 = prefer the pipelined MFMA
-    kernel (million_hip.h: million_set_force_generic)."""
+    """0 / False = auto, 1 / True = scalar fallback kernel only, 2 = grouped MFMA kernel instead of the streaming one
+    (million_hip.h: million_set_force_generic)."""
     L.load().million_set_force_generic(int(on))
 
 

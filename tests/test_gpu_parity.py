@@ -1091,3 +1091,114 @@ def test_device_lengths_are_clamped_not_trusted(policy, env, oracle):
             assert np.array_equal(o[b], np.zeros_like(o[b]))
         else:
             _check(o[b:b + 1], oracle.decode_attn(**cb), f"batch item {b}: lengths {bad[b]} -> {eff[b]}")
+
+
+# ---------------------------------------------------------------- tile kernel: the rest of the binding surface ----------
+_TILE_SHAPES = [(64, 16), (64, 32), (64, 64), (128, 16)]      # (d, M): d_m = 4, 2, 1, 8 (setup.py:12-15 of the reference)
+
+
+def _kind(torch, ops, q, k_res, **kw):
+    from million_amd import _lib
+    desc = ops.make_attn_desc(q, k_res, **kw)
+    return _lib.load().million_attn_kernel_kind(ctypes.byref(desc))
+
+
+@pytest.mark.parametrize("d,M", _TILE_SHAPES, ids=[f"d{d}M{M}" for d, M in _TILE_SHAPES])
+@pytest.mark.parametrize("C", [256, 128])
+@pytest.mark.parametrize("T,r,nh,nhk,bs", [(0, 17, 4, 2, 1), (1, 1, 8, 8, 1), (17, 128, 8, 2, 1), (300, 33, 16, 2, 2),
+                                           (5000, 64, 32, 8, 1), (4097, 0, 6, 2, 1)])
+def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
+    """d = 64 / M = 16 shapes of the reference's build matrix run the tile MFMA kernel (not the scalar fallback):
+    row-major (10-arg layout, transposed once), fully paged at every page size, and the 13-arg mixed layout."""
+    torch, ops = env
+    if T == 0 and r == 0:
+        pytest.skip("nothing to attend")
+    c = synth.attn_case(7000 + d + M + C + T + r, bs, nh, nhk, d, M, C, T, r, Lt=128)
+    gold = oracle.decode_attn(**c)
+    t = _dev(torch, c)
+    if T:
+        assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
+                     v_codes=t["v_codes"]) == 4
+        assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
+                     page_size=64, n_pages_cap=(T + 63) // 64) == 3
+    _check(_run_rowmajor(torch, ops, c, M, C), gold, "tile rowmajor")
+    if T:
+        for ps in (32, 64, 128):
+            _check(_run_paged(torch, ops, oracle, c, M, C, ps), gold, f"tile paged ps={ps}")
+        _check(_run_paged(torch, ops, oracle, c, M, C, 64, k_paged=False, i64=True), gold, "tile mixed i64")
+
+
+@pytest.mark.parametrize("d,M", [(64, 32), (128, 16), (64, 64)], ids=["d64M32", "d128M16", "d64M64"])
+@pytest.mark.parametrize("use_dl", [False, True], ids=["host-lengths", "device-lengths"])
+def test_attn_tile_kernel_ring_append_ragged(d, M, use_dl, env, oracle):
+    """Tile kernel: residual ring (start > 0, wrap), fused append over three steps, per-request device lengths."""
+    torch, ops = env
+    bs, nh, nhk, T, r0, ps, C = 2, 8, 2, 700, 37, 64, 256
+    c = synth.attn_case(7100 + d + M, bs, nh, nhk, d, M, C, T, r0, Lt=128)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    rs = np.random.RandomState(2)
+    start = 100
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    kc, vc = torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda()
+    kw = dict(k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T)
+    # request 1 is shorter than request 0 when the lengths live on the device
+    T1 = 333 if use_dl else T
+    lengths = torch.tensor([[T, r0, start, 0], [T1, r0, start, 0]], dtype=torch.int32, device="cuda") if use_dl else None
+    k_hist, v_hist = c["k_res"].copy(), c["v_res"].copy()
+    r = r0
+    for step in range(3):
+        k_new = rs.standard_normal((bs, nhk, 1, d)).astype(np.float16)
+        v_new = rs.standard_normal((bs, nhk, 1, d)).astype(np.float16)
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0 if use_dl else r, M=M, C=C, resid_start=start,
+                                 dev_lengths=lengths, k_new=torch.from_numpy(k_new).cuda(),
+                                 v_new=torch.from_numpy(v_new).cuda(), **kw)
+        torch.cuda.synchronize()
+        k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
+        r += 1
+        for b, Tb in enumerate((T, T1)):
+            cb = dict(c, q=c["q"][b:b + 1], k_codes=c["k_codes"][b:b + 1, :, :Tb], v_codes=c["v_codes"][b:b + 1, :, :Tb],
+                      k_res=k_hist[b:b + 1], v_res=v_hist[b:b + 1], r=r)
+            _check(out[b:b + 1].cpu().numpy(), oracle.decode_attn(**cb), f"tile fused append step {step} request {b}")
+    got = torch.roll(kr, -start, dims=2).cpu().numpy()
+    np.testing.assert_array_equal(got[:, :, r0:r], k_hist[:, :, r0:r])
+    if use_dl:
+        assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
+
+
+def test_attn_tile_kernel_peaked_and_long(env, oracle):
+    """Tile kernel: a late dominant key forces the running rescale; a long context exercises many tiles per wave and
+    the maximum split count; G = 8 fills the workgroup partial."""
+    torch, ops = env
+    d, M, C = 64, 32, 256
+    c = synth.attn_case(7200, 1, 8, 2, d, M, C, 3000, 9)
+    kc = c["k_cents"].astype(np.float32)
+    q0 = c["q"][0, 0, 0].astype(np.float32).reshape(M, d // M)
+    kc[:, 0, :] = 3.0 * q0
+    c["k_cents"] = kc.astype(np.float16)
+    c["k_codes"][0, 0, 2500, :] = 0
+    c["k_codes"][0, 0, 10, :M // 2] = 0
+    _check(_run_paged(torch, ops, oracle, c, M, C, 64), oracle.decode_attn(**c), "tile peaked")
+    c = synth.attn_case(7201, 1, 16, 2, 128, 16, 256, 40000, 128, Lt=128)
+    _check(_run_paged(torch, ops, oracle, c, 16, 256, 128), oracle.decode_attn(**c), "tile long d128M16 G8")
+    c = synth.attn_case(7202, 2, 8, 8, 64, 16, 128, 33000, 77, Lt=128)
+    _check(_run_rowmajor(torch, ops, c, 16, 128), oracle.decode_attn(**c), "tile long d64M16 bs2")
+
+
+def test_bindings_names_on_tile_shapes(env, oracle):
+    """The generated binding names of the d = 64 / M = 16 part of the reference's build matrix (setup.py:12-15,48-53)."""
+    torch, ops = env
+    import bindings
+    for d, M, C in [(64, 16, 128), (64, 32, 256), (64, 64, 256), (128, 16, 256)]:
+        bs, nh, T, r, Ns = 1, 8, 1000, 17, 8
+        c = synth.attn_case(7300 + d + M, bs, nh, nh, d, M, C, T, r)
+        t = _dev(torch, c)
+        fn = getattr(bindings, f"flash_decoding_allocated_buffer_f16u8_Ns{Ns}Lt{d}d{d}M{M}C{C}")
+        po = torch.empty(bs, nh, Ns + 1, d, dtype=torch.float16, device="cuda")
+        pl = torch.empty(bs, nh, Ns + 1, dtype=torch.float16, device="cuda")
+        out = fn(t["q"], t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"], t["v_res"], r, po, pl)   # Lt = d rows
+        _check(out.cpu().numpy(), oracle.decode_attn(**c), f"bindings d{d}M{M}C{C}")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development helper: time the fused decode-attention launch of ONE library build at several shapes (back-to-back
 launch period over rotating layers, HIP events) and compare its output with the grouped kernel's.
-    MILLION_HIP_LIB=build/ab/libmillion_exp1.so python tools/ab_bench.py [--cfg bs,T,M ...]"""
+    MILLION_HIP_LIB=build/ab/libmillion_exp1.so python tools/ab_bench.py [--cfg bs,T,M[,d] ...] [--vs-scalar]"""
 import argparse
 import os
 import sys
@@ -18,6 +18,7 @@ ap.add_argument("--layers", type=int, default=32)
 ap.add_argument("--shuffle-pages", action="store_true", help="random page permutation (default: ids in allocation order, as PagedPQCache hands them out)")
 ap.add_argument("--iters", type=int, default=96)
 ap.add_argument("--dev-lengths", action="store_true")
+ap.add_argument("--vs-scalar", action="store_true", help="also time the scalar fallback kernel (million_set_force_generic(1)) on the same call")
 ap.add_argument("--bindings-10arg", action="store_true",
                 help="time the reference's 10-argument call (bindings.flash_decoding_allocated_buffer_*: row-major K and V "
                      "codes, the same tensors on every call of a layer) instead of the paged call")
@@ -28,8 +29,10 @@ dev = torch.device("cuda", 0)
 lib = L.load()
 tag = os.environ.get("MILLION_HIP_LIB", "in-tree")
 for cfg in args.cfg:
-    bs, T, M = (int(x) for x in cfg.split(","))
-    nh, nhk, d, C, ps, r = 32, 8, 128, 256, 64, 100
+    f = [int(x) for x in cfg.split(",")]
+    bs, T, M = f[:3]
+    d = f[3] if len(f) > 3 else 128
+    nh, nhk, C, ps, r = 32, 8, 256, 64, 100
     n_pages = (T + ps - 1) // ps
     states = []
     nl = max(4, min(args.layers, int(6e9 // (2 * bs * nhk * n_pages * ps * M))))      # keep the pools under ~6 GB
@@ -66,27 +69,37 @@ for cfg in args.cfg:
         return ops.pq_decode_attn(q, kp, vp, kc, vc, kr, vr, r, M=M, C=C, n_tokens=T, k_page_ids=ids, v_page_ids=ids,
                                   page_size=ps, dev_lengths=dl)
 
-    lib.million_set_force_generic(2)        # grouped kernel as the cross-check
+    lib.million_set_force_generic(2 if (d == 128 and M in (32, 64)) else 1)        # grouped kernel (scalar kernel off the streaming shapes) as the cross-check
     ref = run(0).float()
     lib.million_set_force_generic(0)
     out = run(0).float()
     err = ((out - ref).norm() / ref.norm()).item()
-    for i in range(16):
-        run(i)
-    torch.cuda.synchronize()
-    best = 1e9
-    for rep in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(int(5e7))
-        e0.record()
-        for i in range(args.iters):
+    def timed(iters):
+        for i in range(16):
             run(i)
-        e1.record()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 1e3 / args.iters)
+        best = 1e9
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(int(5e7))
+            e0.record()
+            for i in range(iters):
+                run(i)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+        return best
+
+    best = timed(args.iters)
+    scalar = None
+    if args.vs_scalar:
+        lib.million_set_force_generic(1)
+        scalar = timed(max(4, args.iters // 8))
+        lib.million_set_force_generic(0)
     alg = 2 * bs * nhk * T * M + 2 * bs * nhk * r * d * 2 + 2 * M * C * (d // M) * 2 + bs * nh * d * 4
     if args.bindings_10arg:
         tag = tag + " 10-arg"
-    print(f"{tag:34s} bs={bs} T={T:6d} M={M}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs grouped {err:.1e}", flush=True)
+    extra = f"   scalar fallback {scalar:8.1f} us ({scalar / best:5.1f}x)" if scalar else ""
+    print(f"{tag:34s} bs={bs} T={T:6d} d={d} M={M}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs cross-check {err:.1e}{extra}", flush=True)
     del states
     torch.cuda.empty_cache()
