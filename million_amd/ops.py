@@ -103,6 +103,7 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
     lib = L.load()
     L.check(lib.million_pq_encode(ctypes.byref(desc), X.data_ptr(), cents.data_ptr(), dst.data_ptr(),
                                   _ptr(page_ids), _stream()), "million_pq_encode")
+    _vshadow.pop(id(dst), None)      # written behind torch's back (no version bump): drop a transposed shadow of dst
 
 
 def pq_decode(codes: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:

@@ -1202,3 +1202,49 @@ def test_bindings_names_on_tile_shapes(env, oracle):
         pl = torch.empty(bs, nh, Ns + 1, dtype=torch.float16, device="cuda")
         out = fn(t["q"], t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"], t["v_res"], r, po, pl)   # Lt = d rows
         _check(out.cpu().numpy(), oracle.decode_attn(**c), f"bindings d{d}M{M}C{C}")
+
+
+def test_attn_randomized_sweep(env, oracle):
+    """Seeded sweep over the whole descriptor space of the fused call (both MFMA kernels and the scalar one behind it):
+    d, M, C, group size, batch, context, window fill / capacity / ring start, page size, layout, id width."""
+    torch, ops = env
+    rs = np.random.RandomState(20261004)
+    kinds = set()
+    for it in range(48):
+        d = int(rs.choice([64, 128]))
+        M = int(rs.choice([16, 32, 64]))
+        C = int(rs.choice([128, 256]))
+        nhk = int(rs.choice([1, 2, 4]))
+        G = int(rs.choice([1, 2, 3, 4, 8]))
+        bs = int(rs.choice([1, 2, 3]))
+        T = int(rs.choice([0, 1, 15, 16, 17, 63, 64, 65, 511, 1000, 2049, 3000]))
+        cap = int(rs.choice([64, 128, 256]))
+        r = int(rs.randint(0 if T else 1, cap + 1))
+        start = int(rs.randint(0, cap))
+        ps = int(rs.choice([32, 64, 128]))
+        layout = rs.choice(["rowmajor", "paged", "mixed"]) if T else "rowmajor"
+        c = synth.attn_case(9000 + it, bs, nhk * G, nhk, d, M, C, T, r, Lt=cap)
+        gold = oracle.decode_attn(**c)
+        t = _dev(torch, c)
+        kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+        kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+        vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+        kw = {}
+        kc, vc = t["k_codes"], t["v_codes"]
+        if layout != "rowmajor":
+            vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+            kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+            perm = rs.permutation(vpool.shape[0])
+            vpool, kpool, ids = vpool[perm], kpool[perm], np.argsort(perm)[ids]
+            i64 = bool(rs.randint(2))
+            ids_t = torch.from_numpy(ids.astype(np.int64 if i64 else np.int32)).cuda()
+            vc = torch.from_numpy(vpool).cuda()
+            kw = dict(v_page_ids=ids_t, page_size=ps, n_tokens=T)
+            if layout == "paged":
+                kc = torch.from_numpy(kpool).cuda()
+                kw["k_page_ids"] = ids_t
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, r, M=M, C=C, resid_start=start, **kw)
+        torch.cuda.synchronize()
+        _check(out.cpu().numpy(), gold, f"sweep {it}: d={d} M={M} C={C} nhk={nhk} G={G} bs={bs} T={T} r={r}/{cap}@{start} ps={ps} {layout}")
+        kinds.add((d, M))
+    assert len(kinds) == 6
