@@ -1029,8 +1029,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = blockIdx.x;
-    const int bh = blockIdx.y;
+    // Workgroup i of a grid lands on XCD i % 8 (tools/micro/xcc_map.hip).  With a multiple of 8 (b, kv head) pairs the
+    // pairs are dealt over the linear id first, so ALL splits of a pair run on one XCD and the last arriver can read
+    // the partials through its own L2 (common.h: ticket_and_merge checks the placement at run time, it is never assumed).
+    int split = blockIdx.x, bh = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
+        bh = id % (int)gridDim.y;
+        split = id / (int)gridDim.y;
+    }
     const int b = bh / p.nh_k, hk = bh % p.nh_k;
     const int G = p.G;
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);

@@ -37,7 +37,7 @@ struct AttnParams {
     int *ws_cnt2;          // per-batch second-level ticket
     f16 *out;
     float *ws_part;
-    int *ws_cnt;
+    unsigned long long *ws_cnt;   // per (b, kv head): arrivals of this launch, one byte per XCD (ticket_and_merge)
     const int *__restrict__ dev_lengths;
     int bs, nh, nh_k, G, d, M, C, dm;
     int T, r, rstart, rcap;
@@ -161,7 +161,10 @@ __device__ __forceinline__ float ld_agent(const float *p) {
 // Returns false (nothing done) for shapes it does not cover.
 typedef unsigned mv4u __attribute__((ext_vector_type(4)));
 typedef float mv4f __attribute__((ext_vector_type(4)));
-template <int G_>
+// AUX = cache-policy bits of the loads of handed-off bytes: 16 (sc1, agent scope: the bytes may have been written on
+// another XCD, whose L2 is not coherent with ours - every load goes to memory, ~1.7 us) or 1 (sc0: coherent at THIS
+// XCD's L2) when the tickets say every producer ran on the merger's own XCD (ticket_and_merge).
+template <int G_, int AUX>
 __device__ __forceinline__ void merge_vec4(const AttnParams &p, int b, int hk, const float *src, int ns, float *scratch) {
     constexpr int kThreads = 512, kD = 128;
     constexpr int nq = G_ * kD / 4;            // float4 groups of the output
@@ -176,15 +179,18 @@ __device__ __forceinline__ void merge_vec4(const AttnParams &p, int b, int hk, c
     for (int k = 0; k < kPer; ++k) {
         const int slot = sg + k * nsg;
         const int sl = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load
-        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sl * p.slot_floats + 4 * q) * 4, 0, 16 /* sc1 */);
+        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sl * p.slot_floats + 4 * q) * 4, 0, AUX);
     }
     // softmax weights of the slots (lane = slot), as in the scalar form
     {
         const int lane = tid & 63, wv = tid >> 6;
         for (int gg = wv; gg < G_; gg += kThreads / 64) {
             const bool on = lane < ns;
-            const float m0 = on ? ld_agent(src + (long long)lane * p.slot_floats + G_ * kD + gg) : -INFINITY;
-            const float l0 = on ? ld_agent(src + (long long)lane * p.slot_floats + G_ * kD + G_ + gg) : 0.f;
+            const int sl = on ? lane : 0;                                  // clamped: never a conditional load
+            const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + G_ * kD + gg) * 4, 0, AUX));
+            const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + G_ * kD + G_ + gg) * 4, 0, AUX));
+            const float m0 = on ? m1 : -INFINITY;
+            const float l0 = on ? l1 : 0.f;
             const float mx = wave_max(m0);
             const float ms_ = mx > -INFINITY ? mx : 0.f;
             const float w0 = exp2f(m0 - ms_);
@@ -237,12 +243,20 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const int t = __hip_atomic_fetch_add(p.ws_cnt + bh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag_lds = (t == p.nslots - 1);
+        // One 64-bit counter per (b, kv head), one byte per XCD (<= 65 arrivals): the sum of the bytes is the ticket, and
+        // "only my byte is non-zero" tells the last arriver that every partial was written through ITS OWN L2.
+        const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        const unsigned long long mine = 1ull << (8 * xcc);
+        const unsigned long long now = __hip_atomic_fetch_add(p.ws_cnt + bh, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+        unsigned long long s = (now & 0x00ff00ff00ff00ffull) + ((now >> 8) & 0x00ff00ff00ff00ffull);
+        s = (s & 0x0000ffff0000ffffull) + ((s >> 16) & 0x0000ffff0000ffffull);
+        const int arrived = (int)((s + (s >> 32)) & 0xffffffffull);
+        *flag_lds = arrived != p.nslots ? 0 : (now == ((unsigned long long)p.nslots << (8 * xcc)) ? 2 : 1);
     }
     __syncthreads();
     MILLION_STAMP(p, 10);
-    if (!*flag_lds) return;
+    const int arrival = *flag_lds;      // 0 = not the last, 1 = last, 2 = last and every producer ran on this XCD
+    if (!arrival) return;
 
     // ---- last arriver: merge all slots of (b, hk); every load of handed-off bytes is an sc1 load ----
     // One memory round trip: each thread first requests the values of its output element from up to
@@ -254,10 +268,17 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
     if (nthr == 512 && d == 128 && ns <= 32 && (G == 1 || G == 2 || G == 4 || G == 8)) {      // workgroup-uniform
         MILLION_STAMP(p, 11);
-        if (G == 4) merge_vec4<4>(p, b, hk, src, ns, scratch);
-        else if (G == 8) merge_vec4<8>(p, b, hk, src, ns, scratch);
-        else if (G == 2) merge_vec4<2>(p, b, hk, src, ns, scratch);
-        else merge_vec4<1>(p, b, hk, src, ns, scratch);
+        if (arrival == 2) {               // every producer on this XCD: loads coherent at our L2
+            if (G == 4) merge_vec4<4, 1>(p, b, hk, src, ns, scratch);
+            else if (G == 8) merge_vec4<8, 1>(p, b, hk, src, ns, scratch);
+            else if (G == 2) merge_vec4<2, 1>(p, b, hk, src, ns, scratch);
+            else merge_vec4<1, 1>(p, b, hk, src, ns, scratch);
+        } else {
+            if (G == 4) merge_vec4<4, 16>(p, b, hk, src, ns, scratch);
+            else if (G == 8) merge_vec4<8, 16>(p, b, hk, src, ns, scratch);
+            else if (G == 2) merge_vec4<2, 16>(p, b, hk, src, ns, scratch);
+            else merge_vec4<1, 16>(p, b, hk, src, ns, scratch);
+        }
         goto merged;
     }
     {
@@ -319,7 +340,7 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     }
 merged:
     if (tid == 0) {
-        __hip_atomic_store(p.ws_cnt + bh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.ws_cnt + bh, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // fused append with device-resident lengths: every workgroup of batch b has read its lengths once
         // all nh_k heads have been merged; the last merger advances r
         if (p.k_new && p.dev_lengths_w) {

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void codes_transpose_kernel(const uint8_t *__r
 
 static size_t attn_partial_bytes(int bs, int nh_k, int G, int d) {
     const size_t slot = (size_t)(G * d + 2 * G + 3) / 4 * 4;
-    size_t cnt = (size_t)bs * (nh_k + 1) * sizeof(int);
+    size_t cnt = (size_t)bs * nh_k * sizeof(unsigned long long) + (size_t)bs * sizeof(int);      // tickets per (b, hk) + per b
     cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
     size_t b = cnt + (size_t)bs * nh_k * (kMaxSplits + 1) * slot * sizeof(float);
     return (b + 255) / 256 * 256;
@@ -362,10 +362,10 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.k_new = (const f16 *)k_new; p.v_new = (const f16 *)v_new;
     p.k_res_w = (f16 *)k_resid; p.v_res_w = (f16 *)v_resid;
     p.dev_lengths_w = (int *)desc->dev_lengths;
-    size_t cnt = (size_t)p.bs * (p.nh_k + 1) * sizeof(int);
+    size_t cnt = (size_t)p.bs * p.nh_k * sizeof(unsigned long long) + (size_t)p.bs * sizeof(int);
     cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
-    p.ws_cnt = (int *)workspace;
-    p.ws_cnt2 = p.ws_cnt + p.bs * p.nh_k;
+    p.ws_cnt = (unsigned long long *)workspace;
+    p.ws_cnt2 = (int *)(p.ws_cnt + p.bs * p.nh_k);
     p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
     if (!g_force_generic) {
