@@ -21,7 +21,7 @@
 //   * the waves' partials are merged through LDS, the workgroups' through the workspace by the last arriver
 //     (common.h: publish_and_merge), exactly as in the other two kernels.
 // Code bytes are read once per kv head (all G = nh / nh_k query heads share a workgroup) straight into registers,
-// four tiles ahead; page ids eight tiles ahead.  V must be in transposed pages (the reference's 10-argument row-major call
+// kPF tiles ahead; page ids 2 kPF tiles ahead.  V must be in transposed pages (the reference's 10-argument row-major call
 // is transposed first, million_api.hip).
 #include "common.h"
 
@@ -32,7 +32,10 @@ typedef _Float16 t4f16 __attribute__((ext_vector_type(4)));
 typedef float t4f32 __attribute__((ext_vector_type(4)));
 typedef unsigned t4u __attribute__((ext_vector_type(4)));
 
-constexpr int kTW = 4;     // waves per workgroup
+// Waves per workgroup (template parameter TW): the two codebooks (d*C*2 bytes each) decide.  d = 128: 128 KiB of tables
+// leave room for four 6-KiB wave tiles (one workgroup of 4 waves per CU).  d = 64: 64 KiB of tables: either two
+// workgroups of 4 waves per CU (best throughput: 57 vs 62 us at 4 requests x 32K, M = 32) or one workgroup of 16 waves
+// (fewer tiles per wave, shorter launch when there is little work per CU: 23.9 vs 26.5 us at 1 request).
 constexpr int kTT = 16;    // tokens per wave tile
 
 template <int D>
@@ -42,9 +45,9 @@ struct TileGeom {
     static constexpr int kTile = (kTT * kKRow > D * kVRow) ? kTT * kKRow : D * kVRow;
 };
 
-static size_t tile_lds_bytes(int d, int C, int slot_floats) {
+static size_t tile_lds_bytes(int d, int C, int slot_floats, int waves) {
     const size_t tile = d == 128 ? TileGeom<128>::kTile : TileGeom<64>::kTile;
-    return 2 * (size_t)d * C * 2 + kTW * tile + (size_t)slot_floats * 4 + 16;
+    return 2 * (size_t)d * C * 2 + waves * tile + (size_t)slot_floats * 4 + 16;
 }
 
 __device__ __forceinline__ float fast_exp2_tile(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: exp2(-inf) = 0
@@ -55,8 +58,9 @@ __device__ __forceinline__ void lds_phase() {      // LDS writes of this wave be
     asm volatile("" ::: "memory");
 }
 
-template <int D, int DM>
-__global__ __launch_bounds__(kTW * 64, 2) void attn_tile_kernel(AttnParams p) {
+template <int D, int DM, int TW>
+__global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(AttnParams p) {
+    constexpr int kTW = TW;
     constexpr int M = D / DM;
     constexpr int NS = D / 32;                 // score stages (32 dims each)
     constexpr int NC = D / 16;                 // output tiles of 16 dims
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(kTW * 64, 2) void attn_tile_kernel(AttnParams p) {
             // Code bytes kPF tiles ahead, page ids 2 kPF tiles ahead, in a register ring with compile-time slots (the loop
             // is unrolled by the ring size; a tile is 5-9 registers).  One tile ahead is not enough: an iteration is
             // ~0.6 us of work and a load under traffic takes 1-2 us, so the loop ran at the load latency.
-            constexpr int kPF = 4;
+            constexpr int kPF = TW == 4 ? 4 : 2;       // (sixteen waves per CU hide latency by themselves; <= 128 VGPRs)
             Codes ring[kPF];
             Pids idr[kPF];
 #pragma unroll
@@ -393,7 +397,7 @@ bool attn_tile_supported(const AttnParams &p) {
     const bool shape = (p.d == 128 || p.d == 64) && (p.M == 16 || p.M == 32 || p.M == 64) && (p.C == 128 || p.C == 256) &&
                        p.G <= kMaxG;
     if (!shape || !p.v_paged) return false;
-    return tile_lds_bytes(p.d, p.C, p.slot_floats) <= 160 * 1024;
+    return tile_lds_bytes(p.d, p.C, p.slot_floats, 4) <= 160 * 1024;
 }
 bool attn_tile_shape_ok(const AttnParams &p) {
     AttnParams q = p;
@@ -403,10 +407,14 @@ bool attn_tile_shape_ok(const AttnParams &p) {
 
 int launch_attn_tile(const AttnParams &p_in, hipStream_t s) {
     AttnParams p = p_in;
-    // split policy: one workgroup per CU at d = 128 (the two codebooks fill most of the LDS), two at d = 64; a split is
-    // a multiple of 64 tokens (16-token tiles, four waves) and at least 256 tokens long
+    // d = 64: sixteen waves in one workgroup per CU while a CU has at most 128 tiles to walk, else two 4-wave workgroups
     const int bh = p.bs * p.nh_k;
-    const int target = device_cus() * (p.d == 64 ? 2 : 1);
+    const int cus = device_cus();
+    const bool wide = p.d == 64 && (long long)p.T * bh <= 128ll * kTT * cus;
+    const int waves = wide ? 16 : 4;
+    // split policy: one workgroup per CU (two of the 4-wave ones at d = 64); a split is a multiple of 64 tokens and at
+    // least 256 tokens long
+    const int target = cus * (p.d == 64 && !wide ? 2 : 1);
     int ns = (target + bh - 1) / bh;
     if (ns > kMaxSplits) ns = kMaxSplits;
     int by_len = (p.T + 255) / 256;
@@ -419,26 +427,27 @@ int launch_attn_tile(const AttnParams &p_in, hipStream_t s) {
     p.nsplit = ns;
     p.split_len = len;
     p.nslots = ns + 1;
-    const size_t lds = tile_lds_bytes(p.d, p.C, p.slot_floats);
+    const size_t lds = tile_lds_bytes(p.d, p.C, p.slot_floats, waves);
     if (device_once(2)) {
-        (void)hipFuncSetAttribute((const void *)attn_tile_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_tile_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_tile_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_tile_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_tile_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_tile_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define TILE_ATTR(D_, DM_, TW_) (void)hipFuncSetAttribute((const void *)attn_tile_kernel<D_, DM_, TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        TILE_ATTR(128, 8, 4); TILE_ATTR(128, 4, 4); TILE_ATTR(128, 2, 4);
+        TILE_ATTR(64, 4, 4); TILE_ATTR(64, 2, 4); TILE_ATTR(64, 1, 4);
+        TILE_ATTR(64, 4, 16); TILE_ATTR(64, 2, 16); TILE_ATTR(64, 1, 16);
+#undef TILE_ATTR
     }
-    const dim3 grid(p.nslots, bh), block(kTW * 64);
+    const dim3 grid(p.nslots, bh), block(waves * 64);
+#define TILE_LAUNCH(D_, DM_, TW_) hipLaunchKernelGGL((attn_tile_kernel<D_, DM_, TW_>), grid, block, lds, s, p)
     const int key = p.d * 16 + p.dm;
     switch (key) {
-    case 128 * 16 + 8: hipLaunchKernelGGL((attn_tile_kernel<128, 8>), grid, block, lds, s, p); break;
-    case 128 * 16 + 4: hipLaunchKernelGGL((attn_tile_kernel<128, 4>), grid, block, lds, s, p); break;
-    case 128 * 16 + 2: hipLaunchKernelGGL((attn_tile_kernel<128, 2>), grid, block, lds, s, p); break;
-    case 64 * 16 + 4: hipLaunchKernelGGL((attn_tile_kernel<64, 4>), grid, block, lds, s, p); break;
-    case 64 * 16 + 2: hipLaunchKernelGGL((attn_tile_kernel<64, 2>), grid, block, lds, s, p); break;
-    case 64 * 16 + 1: hipLaunchKernelGGL((attn_tile_kernel<64, 1>), grid, block, lds, s, p); break;
+    case 128 * 16 + 8: TILE_LAUNCH(128, 8, 4); break;
+    case 128 * 16 + 4: TILE_LAUNCH(128, 4, 4); break;
+    case 128 * 16 + 2: TILE_LAUNCH(128, 2, 4); break;
+    case 64 * 16 + 4: if (wide) TILE_LAUNCH(64, 4, 16); else TILE_LAUNCH(64, 4, 4); break;
+    case 64 * 16 + 2: if (wide) TILE_LAUNCH(64, 2, 16); else TILE_LAUNCH(64, 2, 4); break;
+    case 64 * 16 + 1: if (wide) TILE_LAUNCH(64, 1, 16); else TILE_LAUNCH(64, 1, 4); break;
     default: set_error("attn_tile: d=%d d_m=%d", p.d, p.dm); return MILLION_ERR_SHAPE;
     }
+#undef TILE_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("attn_tile launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
     return MILLION_OK;

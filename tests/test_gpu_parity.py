@@ -1187,6 +1187,10 @@ def test_attn_tile_kernel_peaked_and_long(env, oracle):
     _check(_run_paged(torch, ops, oracle, c, 16, 256, 128), oracle.decode_attn(**c), "tile long d128M16 G8")
     c = synth.attn_case(7202, 2, 8, 8, 64, 16, 128, 33000, 77, Lt=128)
     _check(_run_rowmajor(torch, ops, c, 16, 128), oracle.decode_attn(**c), "tile long d64M16 bs2")
+    # d = 64 with more than 128 tiles per CU: the two-workgroups-of-four-waves variant (smaller launches use 16 waves)
+    for M, seed in ((32, 7203), (64, 7204)):
+        c = synth.attn_case(seed, 3, 16, 8, 64, M, 256, 24000, 50, Lt=128)
+        _check(_run_paged(torch, ops, oracle, c, M, 256, 64), oracle.decode_attn(**c), f"tile d64M{M} bs3 4-wave variant")
 
 
 def test_bindings_names_on_tile_shapes(env, oracle):
