@@ -922,33 +922,42 @@ __device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, flo
 template <int N>
 __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float &m_run, float &l_run, v16f32 (&O)[2][2],
                                                    int G, int lane) {
+    // m_run is the softmax REFERENCE of the head, not necessarily its running maximum: it only moves (and O, l are
+    // only rescaled) when some score of the unit exceeds it by more than kHeadroom (log2 units), so that the
+    // probabilities stay <= 2^kHeadroom (fp16 operand of the value MFMA: fine up to 2^15).  The common unit then needs
+    // no cross-lane maximum, no alpha, no rescale: one compare and a wave-uniform branch.  (Any reference gives the same
+    // softmax; the merges downstream only need (m, l, O) to be consistent.)
+    constexpr float kHeadroom = 8.0f;
     float mx = sc[0];
 #pragma unroll
     for (int i = 1; i < N; ++i) mx = fmaxf(mx, sc[i]);
-    mx = rows_max(mx) * c;
-    const float m_new = fmaxf(m_run, mx);
-    const float m_safe = m_new > -INFINITY ? m_new : 0.f;
-    const float alpha = fast_exp2(m_run - m_safe);
-    if (__any(m_new > m_run && m_run > -INFINITY)) {
+    if (__any(mx * c > m_run + kHeadroom)) {            // also the first unit: m_run = -inf
+        const float m_new = fmaxf(m_run, rows_max(mx) * c);
+        const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+        const float alpha = fast_exp2(m_run - m_safe);
+        if (__any(m_new > m_run && m_run > -INFINITY)) {
 #pragma unroll
-        for (int rho = 0; rho < 4; ++rho) {
-            const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
-            const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;
-            const float f = lane < 32 ? flo : fhi;
+            for (int rho = 0; rho < 4; ++rho) {
+                const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
+                const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;
+                const float f = lane < 32 ? flo : fhi;
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
+                    for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
+            }
         }
+        l_run *= alpha;
+        m_run = m_new;
     }
+    const float m_ref = m_run > -INFINITY ? m_run : 0.f;
     float ls = 0.f;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        sc[i] = fast_exp2(fmaf(sc[i], c, -m_safe));
+        sc[i] = fast_exp2(fmaf(sc[i], c, -m_ref));
         ls += sc[i];
     }
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
+    l_run += ls;
 }
 
 // =====================================================================================================

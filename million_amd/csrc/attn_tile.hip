@@ -131,18 +131,22 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
             sc[v] = (4 * q4 + v < n_valid) ? acc[v] * p.scale_log2e : -INFINITY;
             mx = fmaxf(mx, sc[v]);
         }
-        mx = rows_max(mx);                     // over the four lane rows: all 16 tokens of head c16 (n_valid >= 1: finite)
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2_tile(m_run - m_new);
+        // m_run is the softmax reference of head c16, moved (with the cross-lane maximum and the rescale of O, l) only
+        // when a score exceeds it by more than 2^8: the common tile needs no reduction (attn_mfma.hip: softmax_online_raw)
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.0f)) {      // also the first tile: m_run = -inf, mx finite
+            const float m_new = fmaxf(m_run, rows_max(mx));        // over the four lane rows: all 16 tokens of head c16
+            const float alpha = fast_exp2_tile(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                for (int n = 0; n < NC; ++n) O[n] *= alpha;        // O^T[dim][head c16]: this lane's own head
+            }
+        }
         float pe[4], ls = 0.f;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { pe[v] = fast_exp2_tile(sc[v] - m_new); ls += pe[v]; }
-        l_run = l_run * alpha + rows_sum(ls);
-        m_run = m_new;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
-#pragma unroll
-            for (int n = 0; n < NC; ++n) O[n] *= alpha;      // O^T[dim][head c16]: this lane's own head
-        }
+        for (int v = 0; v < 4; ++v) { pe[v] = fast_exp2_tile(sc[v] - m_run); ls += pe[v]; }
+        l_run += ls;                           // per-lane partial sum; the four lane rows are added once, at the end
         return t4f16{(_Float16)pe[0], (_Float16)pe[1], (_Float16)pe[2], (_Float16)pe[3]};
     };
     // ---- step 5: O^T += V^T P ----
@@ -364,13 +368,14 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
     __syncthreads();
     {
         const int wf = G * D + 2 * G;                         // floats per wave
+        const float l_sum = rows_sum(l_run);
         float *ws = (float *)(smem + 2 * tab_bytes) + wave * wf;
         if (c16 < G) {
 #pragma unroll
             for (int n = 0; n < NC; ++n)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) ws[c16 * D + 16 * n + 4 * q4 + v] = O[n][v];
-            if (q4 == 0) { ws[G * D + c16] = m_run; ws[G * D + G + c16] = l_run; }
+            if (q4 == 0) { ws[G * D + c16] = m_run; ws[G * D + G + c16] = l_sum; }
         }
         __syncthreads();
         const float *w0 = (const float *)(smem + 2 * tab_bytes);
