@@ -50,13 +50,14 @@ constexpr int kLdsBytes = kStampOff + kStampWaves * kStampSlots * 8;  // 138 KiB
 constexpr int kResRows = 16;                 // residual-window rows per wave (one MFMA tile): 8 waves x 16 = 128 rows per split
 
 struct UnitCodes {
-    v4u k[2];   // K code bytes: group g2 (16 tokens), lane (q, c): token c, bytes [16q, 16q+16)
+    v4u k[2];   // K code bytes: score tile g2, lane (q, c): tile row c, bytes [16q, 16q+16) of that token's code row
+                // (grouped kernel: row c = token 16 g2 + c; streaming kernel: stream_token_of_row(g2, c))
     v4u v[2];   // V code bytes: half n (32 subspaces), lane (h, c): m = 32n + c, tokens [16h, 16h+16)
 };
 
 // M = 32 (d_m = 4): a token's code row is 32 bytes, a codebook entry 8 bytes (one ds_read_b64)
 struct UnitCodes32 {
-    v2u k[2];   // K code bytes: group g2 (16 tokens), lane (q, c): token c, bytes [8q, 8q+8)
+    v2u k[2];   // K code bytes: score tile g2, lane (q, c): tile row c (see UnitCodes), bytes [8q, 8q+8)
     v4u v[1];   // V code bytes: lane (h, c): subspace m = c, tokens [16h, 16h+16)
 };
 
@@ -827,27 +828,34 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 }
 
 // ---- value side of a 32-token unit in pieces, for the pipelined kernel ---------------------------------
-// value_prep: probabilities (score layout: pr[g2*4 + rho] = token 16*g2 + 4*q' + rho for the head of this lane's
-// column) -> A operands P[s][0..3] of the two token steps (rows = heads, K = 16 tokens).
-__device__ __forceinline__ void value_prep(const float (&pr)[8], unsigned (&P)[2][4]) {
-    unsigned pk[2][2];    // pk[g2][i]: tokens 16*g2 + 4*q' + {2i, 2i+1} as packed fp16
+// The A operand of the value MFMA (rows = heads, K = 16 tokens) wants, in lane (h, head), the probabilities of tokens
+// 16h + 8s + j (token step s, j = 0..7).  The score MFMAs leave pr[4*g2 + rho] = row 4q' + rho of score tile g2 in lane
+// (q', head), and WHICH token a tile row is, is the K gather's choice.  With tile g2, row i = token 8*(i >> 2) + 4*g2 +
+// (i & 3) (stream_token_of_row), lane rows 0 and 2 - the lanes the value MFMA reads for h = 0 / 1 - already hold the
+// eight tokens of step s = 0 in operand order: value_prep is four cvt_pk and nothing else.  Step s = 1 wants what lane
+// rows 1 and 3 hold; value_next_step brings it over IN PLACE with four v_permlane16_swap, once the s = 0 steps have
+// issued.  (Round 1-2 form: tiles of 16 consecutive tokens, 2 permlane32_swap + 4 copies + 4 permlane16_swap per unit.)
+__device__ __forceinline__ int stream_token_of_row(int g2, int i) { return 8 * (i >> 2) + 4 * g2 + (i & 3); }
+__device__ __forceinline__ void value_prep(const float (&pr)[8], unsigned (&P)[4]) {
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             h2 t = {(f16)pr[g2 * 4 + 2 * i], (f16)pr[g2 * 4 + 2 * i + 1]};
-            pk[g2][i] = __builtin_bit_cast(unsigned, t);
+            P[2 * g2 + i] = __builtin_bit_cast(unsigned, t);
         }
+}
+// P (token step 0) -> P (token step 1): lane rows 0 / 2 receive what lane rows 1 / 3 held.  v_permlane16_swap(a, b)
+// returns {a with its odd rows replaced by b's even rows, b with its even rows replaced by a's odd rows}.
+__device__ __forceinline__ void value_next_step(unsigned (&P)[4]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const v2u x = __builtin_amdgcn_permlane32_swap(pk[0][i], pk[1][i], false, false);
-        // x[0] = {grp0 rows 0,1 | grp1 rows 0,1}  (step 0)   x[1] = {grp0 rows 2,3 | grp1 rows 2,3}  (step 1)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const v2u y = swap16_self(x[s]);
-            P[s][i] = y[0];          // rows {0,0,2,2} of x[s]
-            P[s][2 + i] = y[1];      // rows {1,1,3,3} of x[s]
-        }
+    for (int g2 = 0; g2 < 2; ++g2) {
+        const v2u t = __builtin_amdgcn_permlane16_swap(P[2 * g2], P[2 * g2 + 1], false, false);
+        const unsigned v = t[0], s = t[1];      // s rows 0 / 2 = P[2 g2] rows 1 / 3;  s rows 1 / 3 = P[2 g2 + 1] rows 1 / 3
+        const v2u u = __builtin_amdgcn_permlane16_swap(s, v, false, false);
+        const unsigned u0 = u[0], u1 = u[1];
+        P[2 * g2] = u0;                         // rows 0 / 2 = s rows 0 / 2 (kept)
+        P[2 * g2 + 1] = u1;                     // rows 0 / 2 = s rows 1 / 3
     }
 }
 // the 8 centroid gathers of value step st = 2n + s (subspaces 32n.., tokens 16h + 8s + j)
@@ -1125,7 +1133,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     //      re-request that unit (L2 hits, never consumed), so that no code load sits in a conditional ----
     Unit ring[kRing];
     typedef typename std::conditional<MS == 64, gptr_v4u, gptr_v2u>::type KPtr;      // global address space: no FLAT loads
-    const unsigned k_lane_off = ((unsigned)c16 << kLog2M) + (unsigned)(MS / 4) * q4;    // row c16 (+16 for g2 = 1), quarter q4
+    const int krow0 = stream_token_of_row(0, c16);                                      // token of tile row c16 (tile 1: + 4)
+    const unsigned k_lane_off = ((unsigned)krow0 << kLog2M) + (unsigned)(MS / 4) * q4;  // that token's code row, quarter q4
     const unsigned v_lane_off = ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
 #define UNIT_REQ_K(SL, J)                                                                                          \
     {                                                                                                              \
@@ -1135,12 +1144,12 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
             kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << kLog2M));                                \
             _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
-                ring[SL].k[g2] = *(KPtr)(kb_ + k_lane_off + ((16u * g2) << kLog2M));                               \
+                ring[SL].k[g2] = *(KPtr)(kb_ + k_lane_off + ((4u * g2) << kLog2M));                                \
         } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
             const int tu_ = t0 + jc_ * t_step;                                                                     \
             kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
             _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
-                ring[SL].k[g2] = *(KPtr)(kb_ + (((unsigned)min(tu_ + c16 + 16 * g2, T_ld - 1) << kLog2M) +         \
+                ring[SL].k[g2] = *(KPtr)(kb_ + (((unsigned)min(tu_ + krow0 + 4 * g2, T_ld - 1) << kLog2M) +        \
                                                 (unsigned)(MS / 4) * q4));                                         \
         }                                                                                                          \
     }
@@ -1192,14 +1201,21 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3));
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);      // M = 64 only
 
-    unsigned a[2][4], P[2][4];
+    unsigned a[2][4], P[4];
     EBuf e[2];
     float sc[8];
 #define KG(SL, ST) st_kgather<CL2>(ring[SL], ST, kbase, a[(ST) & 1])
 #define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
         as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
-#define VG(SL, I) st_vgather(ring[SL], I, vconst0, vconst1, e[(I) & 1])
-#define VS(I) st_vstep(e[(I) & 1], P[MS == 64 ? ((I) & 1) : (I)], I, O)
+    // value steps run token-step major: i -> st = 2n + s with s = i / (NV / 2), so that P serves both s = 0 steps, is
+    // moved on in place (value_next_step), and then serves both s = 1 steps
+#define VST(I) (MS == 64 ? ((((I) & 1) << 1) | ((I) >> 1)) : (I))
+#define VG(SL, I) st_vgather(ring[SL], VST(I), vconst0, vconst1, e[(I) & 1])
+#define VS(I)                                                                                                      \
+    {                                                                                                              \
+        if ((I) == NV / 2) value_next_step(P);                                                                     \
+        st_vstep(e[(I) & 1], P, VST(I), O);                                                                        \
+    }
     // raw scores of round J out of the accumulators; only the unit that holds token T - 1 (wave-uniform) is masked; a
     // round whose first token is past T - 1 (only the prologue of a wave without whole rounds meets one) gives -inf
 #define SCORES_OUT(J)                                                                                              \
@@ -1209,7 +1225,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[i] = D[i >> 2][i & 3];                                \
         } else {                                                                                                   \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
-                sc[i] = t_u + 16 * (i >> 2) + 4 * q4 + (i & 3) < T ? D[i >> 2][i & 3] : -INFINITY;                 \
+                sc[i] = t_u + 8 * q4 + 4 * (i >> 2) + (i & 3) < T ? D[i >> 2][i & 3] : -INFINITY;                  \
         }                                                                                                          \
     }
     // BLOCK: the value steps of the unit in slot U4 (round J) interleaved with the 8 score stages of the unit in slot
@@ -1220,7 +1236,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
         UNIT_REQ_K(U4, (J) + 4)      /* the K bytes of slot U4 (round J) were consumed by the previous block */    \
         _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                           \
-            VS(i);                                                                                                 \
+            VS(i)                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             if (i + 1 < NV) VG(U4, i + 1); else VG(((U4) + 1) & 3, 0);                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -1239,7 +1255,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #define VALUE_ALONE(U4)                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                               \
         if (i + 1 < NV) VG(U4, i + 1);                                                                             \
-        VS(i);                                                                                                     \
+        VS(i)                                                                                                      \
     }
     // One unit on its own (the up to three units a wave has beyond its whole rounds of four): scores, softmax, values,
     // self-contained, so that the branch around it carries no pipeline state.
@@ -1330,6 +1346,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef KM
 #undef VG
 #undef VS
+#undef VST
 #undef SCORES_OUT
 #undef BLOCK
 #undef VALUE_ALONE
