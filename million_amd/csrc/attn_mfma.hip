@@ -927,23 +927,40 @@ __device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, flo
 
 // same on RAW scores (q.k, masked to -inf where needed): the 1/sqrt(d)*log2(e) factor c > 0 is folded into the exp2
 // argument (one fma per score instead of a multiply and a subtract), the running maximum stays in the scaled domain
+// v_max3_f32 without the two canonicalising v_max x, x that fmaxf() of an MFMA result costs under IEEE mode (the operands
+// are never signalling NaNs); plain asm, not volatile: the scheduler may move it
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// Softmax state of this lane's head in the streaming kernel.  m is the softmax REFERENCE, not necessarily the running
+// maximum: it moves (cross-lane maximum, alpha, rescale of O and l) only when a raw score of the unit exceeds thr_raw =
+// (m + 2^3) / c, i.e. when a probability would exceed 2^8 (fp16 operand of the value MFMA: exact up to 2^15).  The common
+// unit needs no cross-lane reduction: four v_max3, one compare, a wave-uniform branch.  Any reference gives the same
+// softmax; the merges downstream only need (m, l, O) to be consistent.  neg_ref = -(m, or 0 while m = -inf) and thr_raw
+// are kept in registers so that the common path recomputes neither.
+struct SoftRef {
+    float m, l, neg_ref, thr_raw;
+    __device__ __forceinline__ void set(float m_, float l_, float inv_c) {
+        m = m_; l = l_;
+        neg_ref = m_ > -INFINITY ? -m_ : 0.f;
+        thr_raw = (m_ + 8.0f) * inv_c;          // -inf while nothing has been seen: the first finite score moves it
+    }
+};
 template <int N>
-__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float &m_run, float &l_run, v16f32 (&O)[2][2],
+__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float inv_c, SoftRef &st, v16f32 (&O)[2][2],
                                                    int G, int lane) {
-    // m_run is the softmax REFERENCE of the head, not necessarily its running maximum: it only moves (and O, l are
-    // only rescaled) when some score of the unit exceeds it by more than kHeadroom (log2 units), so that the
-    // probabilities stay <= 2^kHeadroom (fp16 operand of the value MFMA: fine up to 2^15).  The common unit then needs
-    // no cross-lane maximum, no alpha, no rescale: one compare and a wave-uniform branch.  (Any reference gives the same
-    // softmax; the merges downstream only need (m, l, O) to be consistent.)
-    constexpr float kHeadroom = 8.0f;
-    float mx = sc[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) mx = fmaxf(mx, sc[i]);
-    if (__any(mx * c > m_run + kHeadroom)) {            // also the first unit: m_run = -inf
-        const float m_new = fmaxf(m_run, rows_max(mx) * c);
+    static_assert(N == 8, "one 32-token unit: 8 scores per lane");
+    float mx = max3_raw(sc[0], sc[1], sc[2]);
+    mx = max3_raw(mx, sc[3], sc[4]);
+    mx = max3_raw(mx, sc[5], sc[6]);
+    mx = max3_raw(mx, sc[7], sc[7]);
+    if (__any(mx > st.thr_raw)) {
+        const float m_new = fmaxf(st.m, rows_max(mx) * c);
         const float m_safe = m_new > -INFINITY ? m_new : 0.f;
-        const float alpha = fast_exp2(m_run - m_safe);
-        if (__any(m_new > m_run && m_run > -INFINITY)) {
+        const float alpha = fast_exp2(st.m - m_safe);
+        if (__any(m_new > st.m && st.m > -INFINITY)) {
 #pragma unroll
             for (int rho = 0; rho < 4; ++rho) {
                 const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
@@ -955,17 +972,15 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
                     for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
             }
         }
-        l_run *= alpha;
-        m_run = m_new;
+        st.set(m_new, st.l * alpha, inv_c);
     }
-    const float m_ref = m_run > -INFINITY ? m_run : 0.f;
     float ls = 0.f;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        sc[i] = fast_exp2(fmaf(sc[i], c, -m_ref));
+        sc[i] = fast_exp2(fmaf(sc[i], c, st.neg_ref));
         ls += sc[i];
     }
-    l_run += ls;
+    st.l += ls;
 }
 
 // =====================================================================================================
@@ -1196,6 +1211,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         value_res_tile(rt, scr, O);
     }
     STAMP(2);
+    const float inv_c = 1.0f / p.scale_log2e;
+    SoftRef sr;
+    sr.set(m_run, l_run, inv_c);
 
     const unsigned kbase = (unsigned)q4 * (64u << CL2);      // quarter q4 of the K row image: its 16 (M = 64) / 8 (M = 32) subspaces
     const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3));
@@ -1249,7 +1267,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         }                                                                                                          \
         UNIT_REQ_V(U4, (J) + 4)                                                                                    \
         SCORES_OUT((J) + 1)                                                                                        \
-        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
+        softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                        \
         value_prep(sc, P);                                                                                         \
     }
 #define VALUE_ALONE(U4)                                                                                            \
@@ -1269,7 +1287,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             if (st + 2 < 8) KG(SL, st + 2);                                                                        \
         }                                                                                                          \
         SCORES_OUT(J)                                                                                              \
-        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);                                        \
+        softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                        \
         value_prep(sc, P);                                                                                         \
         VG(SL, 0);                                                                                                 \
         VALUE_ALONE(SL)                                                                                            \
@@ -1302,7 +1320,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 for (int i = 0; i < 8; ++i) sc[i] = -INFINITY;
             }
         }
-        softmax_online_raw<8>(sc, p.scale_log2e, m_run, l_run, O, G, lane);
+        softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);
         value_prep(sc, P);
         STAMP(16);
         {
@@ -1354,7 +1372,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef UNIT_REQ_K
 #undef UNIT_REQ_V
     STAMP(3);
-    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
+    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l);
 #undef STAMP
 }
 
