@@ -144,8 +144,11 @@ def main():
     bs, nh, nhk, d, M, C, layers = args.batch_per_gpu, args.nh, args.nh_k, 128, args.M, 256, args.layers
     ps, cap = 64, 128
     T0 = args.ctx // ps * ps
-    r0 = window_fill_at_start(cap, args.warmup, args.steps)
-    total_steps = args.warmup + args.steps + 64 + 8
+    # PRE untimed steps come before the caller's W warm-up steps whatever W is: one whole flush period, so that both
+    # captured graphs (plain step, flush step) have been replayed once before anything is timed
+    PRE = 72
+    r0 = window_fill_at_start(cap, args.warmup + PRE, args.steps)
+    total_steps = PRE + args.warmup + args.steps + 64 + 8
     g = torch.Generator(device="cpu").manual_seed(42 + rank)
     cache = PagedPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=layers, d=d, page_size=ps,
                          extended_residual_size=cap, max_tokens=T0 + total_steps + 2 * cap, device=dev)
@@ -195,7 +198,7 @@ def main():
             graphs["flush" if cache.next_step_flushes() else "plain"].replay()
             cache.note_replayed_step()
 
-    for _ in range(args.warmup):
+    for _ in range(PRE + args.warmup):
         one_step()
     n_flush_steps = 0
 
