@@ -23,6 +23,7 @@ ap.add_argument("--bindings-10arg", action="store_true",
                 help="time the reference's 10-argument call (bindings.flash_decoding_allocated_buffer_*: row-major K and V "
                      "codes, the same tensors on every call of a layer) instead of the paged call")
 ap.add_argument("--zero-codes", action="store_true", help="diagnostic: all code bytes 0 (every LDS gather is a broadcast: no bank conflicts)")
+ap.add_argument("--k-conflict-free", action="store_true", help="diagnostic: K codes chosen so that the 64 lanes of every K gather hit 64 different LDS banks (M = 64 streaming kernel)")
 ap.add_argument("--same-page", action="store_true", help="diagnostic: every page id = 0 (codes come from L2, not HBM)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -42,6 +43,11 @@ for cfg in args.cfg:
         ids = (torch.randperm(bs * nhk * n_pages, device=dev) if args.shuffle_pages else torch.arange(bs * nhk * n_pages, device=dev)).to(torch.int32).reshape(bs, nhk, n_pages)
         if args.zero_codes:
             kpool.zero_(); vpool.zero_()
+        if args.k_conflict_free:      # code(t, m) = row of t in its score tile + 16 * (lane group of m): bank = code % 64
+            t = torch.arange(ps, device=dev)
+            row = ((t >> 3) << 2) | (t & 3)
+            grp = (torch.arange(M, device=dev) >> 2) & 3
+            kpool.copy_((row[:, None] % 16 + 16 * grp[None, :]).to(torch.uint8).expand_as(kpool))
         if args.same_page:
             ids.zero_()
         states.append((kpool, vpool, ids))
