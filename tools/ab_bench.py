@@ -15,6 +15,8 @@ from million_amd import _lib as L, ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", nargs="*", default=["1,32768,64", "2,32768,64", "4,32768,64", "1,131072,64", "1,131072,32", "1,32832,64"])
 ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--nh", type=int, default=32)
+ap.add_argument("--nh-k", type=int, default=8)
 ap.add_argument("--shuffle-pages", action="store_true", help="random page permutation (default: ids in allocation order, as PagedPQCache hands them out)")
 ap.add_argument("--iters", type=int, default=96)
 ap.add_argument("--dev-lengths", action="store_true")
@@ -33,7 +35,7 @@ for cfg in args.cfg:
     f = [int(x) for x in cfg.split(",")]
     bs, T, M = f[:3]
     d = f[3] if len(f) > 3 else 128
-    nh, nhk, C, ps, r = 32, 8, 256, 64, 100
+    nh, nhk, C, ps, r = args.nh, args.nh_k, 256, 64, 100
     n_pages = (T + ps - 1) // ps
     states = []
     nl = max(4, min(args.layers, int(6e9 // (2 * bs * nhk * n_pages * ps * M))))      # keep the pools under ~6 GB
