@@ -1252,3 +1252,34 @@ def test_attn_randomized_sweep(env, oracle):
         _check(out.cpu().numpy(), gold, f"sweep {it}: d={d} M={M} C={C} nhk={nhk} G={G} bs={bs} T={T} r={r}/{cap}@{start} ps={ps} {layout}")
         kinds.add((d, M))
     assert len(kinds) == 6
+
+
+def test_two_streams_concurrent_calls(env, oracle):
+    """The library launches on the caller's stream, keeps no per-call global state and wants one workspace per stream of
+    concurrent calls: two streams hammer different shapes (streaming and tile kernels) at the same time."""
+    torch, ops = env
+    cases = [synth.attn_case(9100, 1, 32, 8, 128, 64, 256, 9000, 77, Lt=128),
+             synth.attn_case(9101, 2, 8, 2, 64, 32, 256, 5000, 30, Lt=128)]
+    golds = [oracle.decode_attn(**c) for c in cases]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    state = []
+    for c, (M, C) in zip(cases, ((64, 256), (32, 256))):
+        t = _dev(torch, c)
+        vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], 64)
+        kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], 64)
+        state.append(dict(t=t, kp=ops.prepare_cents(t["k_cents"], cache=False), vp=ops.prepare_cents(t["v_cents"], cache=False),
+                          kc=torch.from_numpy(kpool).cuda(), vc=torch.from_numpy(vpool).cuda(),
+                          ids=torch.from_numpy(ids.astype(np.int32)).cuda(), M=M, C=C, T=c["k_codes"].shape[2], r=c["r"],
+                          outs=[]))
+    torch.cuda.synchronize()
+    for it in range(20):
+        for s, st in zip(streams, state):
+            with torch.cuda.stream(s):
+                t = st["t"]
+                st["outs"].append(ops.pq_decode_attn(t["q"], st["kc"], st["vc"], st["kp"], st["vp"], t["k_res"], t["v_res"],
+                                                     st["r"], M=st["M"], C=st["C"], n_tokens=st["T"], k_page_ids=st["ids"],
+                                                     v_page_ids=st["ids"], page_size=64))
+    torch.cuda.synchronize()
+    for st, gold in zip(state, golds):
+        for i, o in enumerate(st["outs"]):
+            _check(o.cpu().numpy(), gold, f"stream call {i}")
