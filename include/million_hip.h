@@ -143,7 +143,7 @@ enum {
 
 typedef struct {
     uint32_t struct_size;         /* = sizeof(million_attn_desc) */
-    int32_t bs, nh, nh_k;
+    int32_t bs, nh, nh_k;         /* any nh / nh_k >= 1: more than 8 query heads per kv head run as several launches inside the call */
     int32_t d, M, C;
     int32_t n_tokens;             /* T: quantised tokens per (b, hk); upper bound if dev_lengths != NULL */
     int32_t r;                    /* valid residual rows, 0 <= r <= resid_cap */

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kGenBlock) void attn_generic_kernel(AttnParams p) {
         p.v_res_w[o] = p.v_new[(long long)bh * d + tid];
     }
     for (int g = 0; g < G; ++g) {
-        const int h = hk * G + g;
+        const int h = head0(p, hk) + g;
         const f16 *qv = p.q + ((long long)b * p.nh + h) * d;
         __syncthreads();
         for (int i = tid; i < d; i += kGenBlock) qs[i] = (float)qv[i];

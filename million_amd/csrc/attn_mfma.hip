@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     // B operand of the score MFMA: the query heads (cols), K = 32 dims per step.
     v8f16 qb[4];
     {
-        const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
+        const f16 *qv = p.q + ((long long)b * p.nh + head0(p, hk) + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             v4u t = *(const v4u *)(qv + 8 * s);
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     v8f16 qb[4];
     {
-        const f16 *qv = p.q + ((long long)b * p.nh + hk * G + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
+        const f16 *qv = p.q + ((long long)b * p.nh + head0(p, hk) + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             v4u t = *(const v4u *)(qv + 8 * s);

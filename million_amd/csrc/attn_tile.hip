@@ -107,7 +107,7 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         t4u z = {0u, 0u, 0u, 0u};
-        if (c16 < G) z = *(const t4u *)(p.q + ((long long)b * p.nh + hk * G + c16) * D + 32 * s + 8 * q4);
+        if (c16 < G) z = *(const t4u *)(p.q + ((long long)b * p.nh + head0(p, hk) + c16) * D + 32 * s + 8 * q4);
         qb[s] = __builtin_bit_cast(t8f16, z);
     }
     __syncthreads();

@@ -39,7 +39,8 @@ struct AttnParams {
     float *ws_part;
     unsigned long long *ws_cnt;   // per (b, kv head): arrivals of this launch, one byte per XCD (ticket_and_merge)
     const int *__restrict__ dev_lengths;
-    int bs, nh, nh_k, G, d, M, C, dm;
+    int bs, nh, nh_k, G, d, M, C, dm;   // G: query heads of a kv head served by THIS launch (<= kMaxG)
+    int Gt, g0;                         // nh / nh_k, and the first of them this launch serves (query-head groups > kMaxG: several launches)
     int T, r, rstart, rcap;
     long long res_sb, res_sh, k_sb, k_sh, v_sb, v_sh;
     int k_paged, v_paged, page_size, ps_shift, n_pages_cap, ids64;
@@ -98,6 +99,9 @@ __device__ __forceinline__ float rows_sum(float x) {
     const unsigned b0 = b[0], b1 = b[1];
     return __uint_as_float(b0) + __uint_as_float(b1);
 }
+// first query head (row of q / out) of kv head hk in this launch
+__device__ __forceinline__ int head0(const AttnParams &p, int hk) { return hk * p.Gt + p.g0; }
+
 // Device-resident lengths are not trusted: T is clamped to the host bound the grid was sized for, r to the window
 // capacity (minus the row a fused append is about to add), the ring start to [0, cap).  Out-of-range values become a
 // shorter context / window, never an out-of-bounds read.
@@ -215,7 +219,7 @@ __device__ __forceinline__ void merge_vec4(const AttnParams &p, int b, int hk, c
         for (int j = 1; j < nsg; ++j) acc += red[j * nq + q];
         typedef f16 h4 __attribute__((ext_vector_type(4)));
         const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-        *(h4 *)(p.out + ((long long)b * p.nh + hk * G_) * kD + 4 * q) = o;
+        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk)) * kD + 4 * q) = o;
     }
 }
 
@@ -320,7 +324,7 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
                 const float w = k < ns ? scratch[k * G + g] : 0.f;
                 acc = fmaf(w, v[k], acc);
             }
-            p.out[((long long)b * p.nh + hk * G + g) * d + (tid - g * d)] = (f16)acc;
+            p.out[((long long)b * p.nh + head0(p, hk) + g) * d + (tid - g * d)] = (f16)acc;
         }
     } else {
         for (int e = tid; e < G * d; e += nthr) {
@@ -334,7 +338,7 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
                 for (int k = 0; k < kMergeBatch; ++k)
                     if (s0 + k < ns) acc = fmaf(scratch[(s0 + k) * G + g], v[k], acc);
             }
-            p.out[((long long)b * p.nh + hk * G + g) * d + (e - g * d)] = (f16)acc;
+            p.out[((long long)b * p.nh + head0(p, hk) + g) * d + (e - g * d)] = (f16)acc;
         }
     }
     }

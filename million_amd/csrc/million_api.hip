@@ -144,8 +144,9 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     memset(&p, 0, sizeof(p));
     p.bs = desc->bs; p.nh = desc->nh; p.nh_k = desc->nh_k; p.d = desc->d; p.M = desc->M; p.C = desc->C;
     if (p.bs <= 0 || p.nh <= 0 || p.nh_k <= 0 || p.nh % p.nh_k) { set_error("attn: bs=%d nh=%d nh_k=%d", p.bs, p.nh, p.nh_k); return MILLION_ERR_SHAPE; }
-    p.G = p.nh / p.nh_k;
-    if (p.G > kMaxG) { set_error("attn: nh/nh_k=%d > %d", p.G, kMaxG); return MILLION_ERR_SHAPE; }
+    p.Gt = p.nh / p.nh_k;                     // any group size: more than kMaxG query heads per kv head run as several
+    p.G = p.Gt < kMaxG ? p.Gt : kMaxG;        // launches of up to kMaxG heads (attn_impl); G = heads of the (first) launch
+    p.g0 = 0;
     if (p.M <= 0 || p.d <= 0 || p.d % p.M || p.M % 4) { set_error("attn: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
     p.dm = p.d / p.M;
     if (p.C < 2 || p.C > 256) { set_error("attn: C=%d (uint8 codes)", p.C); return MILLION_ERR_SHAPE; }
@@ -302,7 +303,7 @@ int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh
 
 size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
     if (!desc || desc->nh_k <= 0 || desc->nh % desc->nh_k) return 0;
-    const int G = desc->nh / desc->nh_k;
+    const int Gt = desc->nh / desc->nh_k, G = Gt < kMaxG ? Gt : kMaxG;
     size_t bytes = attn_partial_bytes(desc->bs, desc->nh_k, G, desc->d);
     // row-major V on the MFMA shapes: room for the transposed copy of the V codes (64-token pages)
     if (desc->v_layout == MILLION_KV_ROWMAJOR && desc->k_layout == MILLION_KV_ROWMAJOR && desc->n_tokens > 0 && desc->M > 0)
@@ -326,6 +327,22 @@ int million_attn_kernel_kind(const million_attn_desc *desc) {
     if (attn_tile_supported(p)) return 3;                                             // tile kernel
     if (attn_tile_shape_ok(p) && !p.v_paged && !p.k_paged) return 4;                  // transpose + tile kernel
     return 0;
+}
+
+// one query-head group (p.G <= kMaxG heads per kv head from p.g0 on): 1. the streaming / grouped MFMA kernels (d = 128,
+// M in {64, 32}); 2. the tile kernel (every other shape of the binding surface); 3. the scalar kernel
+static int launch_group(const AttnParams &p, hipStream_t stream) {
+    if (!g_force_generic) {
+        if (attn_mfma_supported(p)) {
+            const int rc_fast = launch_attn_mfma(p, stream);
+            if (rc_fast != kAttnNotHandled) return rc_fast;
+        }
+        if (attn_tile_supported(p)) return launch_attn_tile(p, stream);
+    }
+    AttnParams g = p;
+    choose_splits(g, 256);
+    g.nslots = g.nsplit + 1;
+    return launch_attn_generic(g, stream);
 }
 
 static int attn_impl(const million_attn_desc *desc, const void *q, const void *k_new, const void *v_new,
@@ -368,37 +385,37 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.ws_cnt2 = (int *)(p.ws_cnt + p.bs * p.nh_k);
     p.dbg = g_dbg;
     p.ws_part = (float *)((char *)workspace + cnt);
-    if (!g_force_generic) {
-        // 1. the streaming / grouped MFMA kernels (d = 128, M in {64, 32}); 2. the tile kernel (every other shape of
-        // the binding surface); both want V in transposed pages: the reference's 10-arg row-major layout is
-        // transposed into scratch pages first
-        if (attn_mfma_supported(p)) {
-            const int rc_fast = launch_attn_mfma(p, (hipStream_t)stream);
-            if (rc_fast != kAttnNotHandled) return rc_fast;
-        }
-        if (attn_tile_supported(p)) return launch_attn_tile(p, (hipStream_t)stream);
-        if (!p.v_paged && !p.k_paged && (attn_mfma_shape_ok(p) || attn_tile_shape_ok(p))) {
-            AttnParams pt = p;
-            pt.v_paged = 1; pt.v_identity = 1; pt.page_size = 64; pt.ps_shift = 6;
-            pt.n_pages_cap = p.T > 0 ? (p.T + 63) / 64 : 1;
-            if (p.T > 0) {
-                uint8_t *scratch = (uint8_t *)workspace + attn_partial_bytes(p.bs, p.nh_k, p.G, p.d);
-                hipLaunchKernelGGL(codes_transpose_kernel, dim3(pt.n_pages_cap, p.bs * p.nh_k), dim3(256), 0, (hipStream_t)stream,
-                                   p.v_codes, scratch, p.nh_k, p.T, p.M, p.v_sb, p.v_sh, pt.n_pages_cap);
-                const hipError_t e = hipGetLastError();
-                if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
-                pt.v_codes = scratch;
-            }
-            if (p.T > 0 && attn_mfma_shape_ok(p)) {
-                const int rc_fast = launch_attn_mfma(pt, (hipStream_t)stream);
-                if (rc_fast != kAttnNotHandled) return rc_fast;
-            }
-            if (attn_tile_supported(pt)) return launch_attn_tile(pt, (hipStream_t)stream);
+    // The fast kernels want V in transposed pages: the reference's 10-arg row-major layout is transposed into scratch
+    // pages first (once per call, whatever the number of query-head groups below).
+    AttnParams pl = p;
+    if (!g_force_generic && !p.v_paged && !p.k_paged && (attn_mfma_shape_ok(p) || attn_tile_shape_ok(p))) {
+        pl.v_paged = 1; pl.v_identity = 1; pl.page_size = 64; pl.ps_shift = 6;
+        pl.n_pages_cap = p.T > 0 ? (p.T + 63) / 64 : 1;
+        if (p.T > 0) {
+            uint8_t *scratch = (uint8_t *)workspace + attn_partial_bytes(p.bs, p.nh_k, p.G, p.d);
+            hipLaunchKernelGGL(codes_transpose_kernel, dim3(pl.n_pages_cap, p.bs * p.nh_k), dim3(256), 0, (hipStream_t)stream,
+                               p.v_codes, scratch, p.nh_k, p.T, p.M, p.v_sb, p.v_sh, pl.n_pages_cap);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { set_error("codes_transpose launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+            pl.v_codes = scratch;
         }
     }
-    choose_splits(p, 256);
-    p.nslots = p.nsplit + 1;
-    return launch_attn_generic(p, (hipStream_t)stream);
+    // One launch serves up to kMaxG query heads per kv head; bigger groups (nh / nh_k = 16, ...) run as several launches
+    // on the same stream and workspace, each re-reading the codes.  A fused append happens in the first one: the later
+    // ones find the row in the window (r + 1 rows; device-resident lengths were advanced by the first launch).
+    for (int g0 = 0; g0 < p.Gt; g0 += kMaxG) {
+        AttnParams pg = pl;
+        pg.g0 = g0;
+        pg.G = p.Gt - g0 < kMaxG ? p.Gt - g0 : kMaxG;
+        pg.slot_floats = (pg.G * pg.d + 2 * pg.G + 3) / 4 * 4;
+        if (g0 > 0 && pg.k_new) {
+            pg.k_new = pg.v_new = nullptr;
+            if (!pg.dev_lengths) pg.r += 1;
+        }
+        const int rc_g = launch_group(pg, (hipStream_t)stream);
+        if (rc_g != MILLION_OK) return rc_g;
+    }
+    return MILLION_OK;
 }
 
 int million_pq_decode_attn(const million_attn_desc *desc, const void *q, const void *k_codes, const void *v_codes,

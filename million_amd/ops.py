@@ -312,7 +312,7 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
         _check_rowmajor("value_codes", v_codes, M, n_tokens)
     v_dense = False
     if (not v_paged and not k_paged and n_tokens > 0 and C in (128, 256) and q.shape[3] in (64, 128) and M in (16, 32, 64)
-            and q.shape[1] // nh_k <= 8 and dev_lengths is None):
+            and dev_lengths is None):
         # the reference's 10-argument layout on the MFMA shapes (streaming and tile kernels: the whole binding surface):
         # transposed pages of V, made once per code tensor
         v_codes = _v_pages_of(v_codes, n_tokens)

@@ -1283,3 +1283,54 @@ def test_two_streams_concurrent_calls(env, oracle):
     for st, gold in zip(state, golds):
         for i, o in enumerate(st["outs"]):
             _check(o.cpu().numpy(), gold, f"stream call {i}")
+
+
+@pytest.mark.parametrize("G", [12, 16, 32])
+@pytest.mark.parametrize("d,M", [(128, 64), (128, 32), (64, 32), (128, 16)], ids=["stream64", "stream32", "tile-d64", "tile-m16"])
+def test_attn_query_groups_above_eight(G, d, M, env, oracle):
+    """nh / nh_k > 8 (e.g. 128 query heads over 8 kv heads): served as several launches of up to 8 heads per kv head; the
+    reference takes any group size (one kernel block per query head, Kernel.cuh:44-52)."""
+    torch, ops = env
+    nhk, T, r, C = 2, 1500, 40, 256
+    c = synth.attn_case(9200 + G + d + M, 2, G * nhk, nhk, d, M, C, T, r, Lt=128)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, M, C, 64), gold, f"G={G} paged")
+    _check(_run_rowmajor(torch, ops, c, M, C), gold, f"G={G} rowmajor")
+    ops.set_force_generic(True)
+    try:
+        _check(_run_rowmajor(torch, ops, c, M, C), gold, f"G={G} scalar kernel")
+    finally:
+        ops.set_force_generic(False)
+
+
+@pytest.mark.parametrize("use_dl", [False, True], ids=["host-lengths", "device-lengths"])
+def test_fused_append_with_sixteen_heads_per_kv_head(use_dl, env, oracle):
+    """Fused append with two launches per call (G = 16): the row is appended once, both head groups attend to it, and
+    device-resident r advances by exactly one per call."""
+    torch, ops = env
+    bs, nhk, G, d, M, C, T, r0, ps = 2, 2, 16, 128, 64, 256, 700, 37, 64
+    c = synth.attn_case(9300, bs, G * nhk, nhk, d, M, C, T, r0, Lt=128)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    rs = np.random.RandomState(4)
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    kc, vc = torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda()
+    kr, vr = t["k_res"].clone(), t["v_res"].clone()
+    lengths = torch.tensor([[T, r0, 0, 0]] * bs, dtype=torch.int32, device="cuda") if use_dl else None
+    k_hist, v_hist = c["k_res"].copy(), c["v_res"].copy()
+    r = r0
+    for step in range(3):
+        k_new = rs.standard_normal((bs, nhk, 1, d)).astype(np.float16)
+        v_new = rs.standard_normal((bs, nhk, 1, d)).astype(np.float16)
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0 if use_dl else r, M=M, C=C, dev_lengths=lengths,
+                                 k_new=torch.from_numpy(k_new).cuda(), v_new=torch.from_numpy(v_new).cuda(),
+                                 k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T)
+        torch.cuda.synchronize()
+        k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
+        r += 1
+        _check(out.cpu().numpy(), oracle.decode_attn(**dict(c, k_res=k_hist, v_res=v_hist, r=r)), f"G=16 fused append step {step}")
+    np.testing.assert_array_equal(kr.cpu().numpy()[:, :, r0:r], k_hist[:, :, r0:r])
+    if use_dl:
+        assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
