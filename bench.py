@@ -280,6 +280,9 @@ def main():
                                    "step = 32 x (append + flush-when-full encode + fused decode attention)",
                        "ctx": T0, "layers": layers, "M": M, "batch_per_gpu": bs, "parallelism": f"requests x{world}",
                        "ranks_seen": seen, "window_fill_at_start": r0,
+                       "weak_scaling_base": ("this line" if world == 1 else
+                                             f"per-GPU batch {bs} (BASELINE configs[3] = 16 requests over 8 GPUs): the like-for-like "
+                                             f"1-GPU base is `bench.py --gpus 1 --batch-per-gpu {bs}`, not the default configs[2] line"),
                        "flush_steps_in_timed_region": flushes_timed,
                        "steady_state_64_steps": {"value": round(value64, 2), "ms_per_step": round(ms64, 4),
                                                  "note": "one whole flush period (63 plain steps + 1 flush step)"},
