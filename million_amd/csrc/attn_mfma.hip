@@ -1116,14 +1116,18 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
         new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
     }
-    // the K codebook goes out before anything that depends on a length or a page id (the CU's load path takes ~28 cycles
-    // per 1-KiB wave request, in order: what is requested first is there first)
+    // both codebooks go out before anything that depends on a length or a page id (the CU's load path takes ~28 cycles
+    // per 1-KiB wave request, in order: what is requested first is there first).  (Through round 2 the V codebook was
+    // requested during the prologue and had a barrier of its own: 18.6 -> 18.2 us at one request with it up here.)
     v4u tabk[NT], tabv[NT];
     const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
     {
         const v4u *ks = (const v4u *)p.k_tab;
 #pragma unroll
         for (int i = 0; i < NT; ++i) tabk[i] = ks[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
+        const v4u *vs = (const v4u *)p.v_tab_col;      // the V codebook right behind it: one barrier serves both
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tabv[i] = vs[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
     }
     if (p.dev_lengths)      // issue + wait in ONE statement (see load_pids4); only the masks and the window depend on it
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
@@ -1184,6 +1188,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         v4u *ld = (v4u *)smem;
 #pragma unroll
         for (int i = 0; i < NT; ++i) ld[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabk[i];
+        v4u *ldv = (v4u *)(smem + kVBase);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) ldv[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabv[i];
     }
     STAMP(8);
     __syncthreads();
@@ -1295,20 +1302,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const int n_whole = n_mine >> 2, n_rem = n_mine & 3;      // whole rounds of four units + up to three more
     {
         // prologue: the 8 score stages of round 0 (masked out when the wave has no whole round: its units are all
-        // handled as single units below); the V codebook and round 2 are requested in between
+        // handled as single units below); round 2 is requested in between
         {
-            const v4u *vs = (const v4u *)p.v_tab_col;
             v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             KG(0, 0);
             KG(0, 1);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                // the codebook requests first: its LDS store waits for everything requested before it, and
-                // must not wait for HBM-bound code bytes
-                if (2 * st < NT) {
-                    tabv[2 * st] = vs[((2 * st + rot) & (NT - 1)) * (kNW * 64) + tid];
-                    tabv[2 * st + 1] = vs[((2 * st + 1 + rot) & (NT - 1)) * (kNW * 64) + tid];
-                }
                 KM(st);
                 if (st + 2 < 8) KG(0, st + 2);
                 if (st == 4) UNIT_REQ(2, 2)
@@ -1323,14 +1323,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);
         value_prep(sc, P);
         STAMP(16);
-        {
-            v4u *ldv = (v4u *)(smem + kVBase);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) ldv[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabv[i];
-        }
-        STAMP(12);
-        __syncthreads();
-        STAMP(13);
         UNIT_REQ(3, 3)
         if (n_whole > 0) {
             VG(0, 0);

@@ -77,10 +77,10 @@ if args.grouped:     # labels of the grouped kernel (attn_mfma_kernel)
              (13, "barrier 2"), (3, "residual tile values, value pass (+ later groups)"),
              (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
 else:                # labels of the streaming kernel (attn_stream_kernel)
-    order = [(0, "kernel start"), (7, "requested: page ids, q, K codebook, residual tile, units 0-1"),
-             (8, "K codebook written to LDS"), (1, "barrier 1 (K codebook)"), (2, "residual tile done"),
-             (16, "prologue: scores of unit 0 (+ V codebook / unit 1-2 requests), softmax"),
-             (12, "V codebook written to LDS"), (13, "barrier 2 (V codebook)"), (17, "first whole round of 4 blocks (splits of >= 8 units per wave)"),
+    order = [(0, "kernel start"), (7, "requested: page ids, q, both codebooks, residual tile, units 0-1"),
+             (8, "codebooks written to LDS"), (1, "barrier (codebooks)"), (2, "residual tile done"),
+             (16, "prologue: scores of unit 0 (+ unit 2 requests), softmax"),
+             (17, "first whole round of 4 blocks (splits of >= 8 units per wave)"),
              (19, "blocks of the last whole round"),
              (3, "values of the last unit of the round (+ single units beyond the whole rounds)"),
              (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
