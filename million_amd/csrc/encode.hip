@@ -46,6 +46,9 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
     const int tc = valid ? t : p.n - 1;
     int tok0 = p.tok0, xrow_start = p.xrow_start;
     if (p.dev_lengths) { tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2]; }
+    // device-resident values are not trusted: a ring start outside [0, xrow_mod) becomes 0, a destination token outside
+    // the page table (or negative) drops the store (below)
+    if (p.xrow_mod > 0 && (unsigned)xrow_start >= (unsigned)p.xrow_mod) xrow_start = 0;
     const int xrow = p.xrow_mod > 0 ? (xrow_start + tc) % p.xrow_mod : tc;
     const f16 *xp = p.x + b * p.xsb + hk * p.xsh + (long long)xrow * p.xsn + m0 * DM;
     const int nsub = p.M - m0 < kEncSub ? p.M - m0 : kEncSub;      // wave-uniform
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_kernel(EncParams p) {
     }
     if (!valid) return;
     const int tok = tok0 + t;
+    if (tok0 < 0 || (p.layout != MILLION_CODES_ROWMAJOR && tok / p.page_size >= p.n_pages_cap)) return;
     CodeT *dst = (CodeT *)p.dst;      // strides dsb / dsh are in bytes
     if (p.layout == MILLION_CODES_VPAGES) {
         const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
@@ -147,6 +151,7 @@ __device__ __forceinline__ void encode_small_body(const EncParams &p, int m, int
     const int tc = valid ? t : p.n - 1;
     int tok0 = p.tok0, xrow_start = p.xrow_start;
     if (p.dev_lengths) { tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2]; }
+    if (p.xrow_mod > 0 && (unsigned)xrow_start >= (unsigned)p.xrow_mod) xrow_start = 0;      // not trusted (see pq_encode_kernel)
     const int xrow = p.xrow_mod > 0 ? (xrow_start + tc) % p.xrow_mod : tc;
     const f16 *xp = p.x + b * p.xsb + hk * p.xsh + (long long)xrow * p.xsn + m * DM;
     float x[DM];
@@ -177,9 +182,11 @@ __device__ __forceinline__ void encode_small_body(const EncParams &p, int m, int
         if (dj < best) { best = dj; best_c = cand_c[j][lane]; }
     }
     const int tok = tok0 + t;
+    if (tok0 < 0) return;
     if (p.layout == MILLION_CODES_ROWMAJOR) {
         p.dst[b * p.dsb + hk * p.dsh + (long long)tok * p.M + m] = (uint8_t)best_c;
     } else {
+        if (tok / p.page_size >= p.n_pages_cap) return;
         const long long pid = p.page_ids[(long long)bh * p.n_pages_cap + tok / p.page_size];
         const int off = tok % p.page_size;
         if (p.layout == MILLION_CODES_KPAGES) p.dst[(pid * p.page_size + off) * p.M + m] = (uint8_t)best_c;
@@ -197,32 +204,128 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p)
 }
 
 // ---- one launch per flush (reference flush_to_pages, paged_pq_utils.py:130-210: encode the oldest page of K rows, of
-// V rows, then move the window): blockIdx.y < M encodes K subspace y, otherwise V subspace y - M; the workgroup that
-// finishes last (ticket in the spare 4th word of the batch item's device lengths, reset by that workgroup) advances the
-// lengths - every workgroup has read them by then.  Replaces 3 launches per layer (2 x encode + lengths_advance).
+// V rows, then move the window).
+//
+// Round-3 form.  The round-2 kernel ran one 256-thread workgroup per (head, side, subspace): 1024 workgroups whose
+// lengths ticket was 1024 same-address atomics (~11 ns each at the memory side: ~11 us of fan-in) behind FIVE dependent
+// cold round trips (codebook row -> lengths -> window rows -> page id -> ticket): 18.8 us per launch inside a decode step
+// (rocprofv3, profiles/r02_kernel_stats.csv), 7.5 us only when replayed back to back with warm caches.  Now:
+//   * a workgroup = (64-token block, side, subspace, group of HP kv heads), 16 waves: wave = (head, part of the
+//     centroid range); the subspace's codebook row is fetched once per workgroup, not once per head;
+//   * everything that does not depend on the lengths is requested first; the window rows and the page id follow the
+//     lengths in ONE round trip;
+//   * the ticket (4th word of the batch item's device lengths) is taken as soon as every wave of the workgroup HAS READ
+//     the lengths - all it protects - so its fan-in (<= 256 arrivals) overlaps the centroid scan; the workgroup whose
+//     ticket was last advances the lengths at its end.
+// Codes are bit-identical to pq_encode_kernel / the oracle: same IEEE operations in the same order per (row, centroid),
+// strict '<' over increasing c within a part, parts combined in centroid order.
+constexpr int kFlushWaves = 16;
 struct FlushParams {
     EncParams k, v;
     int *dev_lengths_w;      // writable alias of k.dev_lengths (null: host lengths, nothing to advance)
     int n_flush, rcap;
+    int hp;                  // kv heads per workgroup (1..16)
+    int hgroups;             // ceil(nh_k / hp)
 };
 
 template <int DM>
-__global__ __launch_bounds__(kEncBlock) void pq_flush_kernel(FlushParams f) {
+__global__ __launch_bounds__(kFlushWaves * 64) void pq_flush_kernel(FlushParams f) {
+    __shared__ float rows[256 * DM];
+    __shared__ float cand_d[kFlushWaves][64];
+    __shared__ int cand_c[kFlushWaves][64];
     const int M = f.k.M;
-    const bool vside = (int)blockIdx.y >= M;                    // workgroup-uniform
-    const int bh = blockIdx.z;
-    encode_small_body<DM>(vside ? f.v : f.k, vside ? blockIdx.y - M : blockIdx.y, bh, blockIdx.x);
-    if (!f.dev_lengths_w) return;
-    __syncthreads();      // every wave of this workgroup has read the lengths and issued its stores
-    if (threadIdx.x == 0) {
-        const int b = bh / f.k.nh_k;
-        int *dl = f.dev_lengths_w + b * 4;
-        const int total = (int)(gridDim.x * gridDim.y) * f.k.nh_k;      // workgroups that read batch item b's lengths
-        const int t = __hip_atomic_fetch_add(dl + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == total - 1) {
-            dl[0] += f.n_flush;
-            dl[1] -= f.n_flush;
-            dl[2] = (dl[2] + f.n_flush) % f.rcap;
+    const int side_m = (int)blockIdx.y / f.hgroups, hgrp = (int)blockIdx.y % f.hgroups;
+    const bool vside = side_m >= M;                              // workgroup-uniform
+    const EncParams &p = vside ? f.v : f.k;
+    const int m = vside ? side_m - M : side_m;
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int hp = f.hp;
+    const int parts = kFlushWaves / hp;                          // >= 1 (host: hp <= 16)
+    const int hl = w % hp, part = w / hp;                        // waves beyond hp * parts idle
+    const int hk = hgrp * hp + hl;
+    const bool active = part < parts && hk < p.nh_k;             // wave-uniform
+    const int C = p.C;
+    // (1) independent of the lengths: this subspace's codebook row (one element per thread)
+    const f16 *cm = p.cents + (long long)m * C * DM;
+    f16 cv = (f16)0.f;
+    if ((int)threadIdx.x < C * DM) cv = cm[threadIdx.x];
+    // (2) lengths -> window row of this lane and the page id of the destination token, one round trip
+    int tok0 = p.tok0, xrow_start = p.xrow_start;
+    if (p.dev_lengths) { tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2]; }
+    // device-resident values are not trusted (cf. clamp_lengths): a start outside the ring becomes 0, a destination
+    // outside the page table drops the store
+    if (p.xrow_mod > 0 && (unsigned)xrow_start >= (unsigned)p.xrow_mod) xrow_start = 0;
+    const int t = blockIdx.x * 64 + lane;
+    const bool valid = t < p.n;
+    const int tc = valid ? t : p.n - 1;
+    int xrow = xrow_start + tc;
+    if (p.xrow_mod > 0) xrow %= p.xrow_mod;
+    const int hkc = hk < p.nh_k ? hk : p.nh_k - 1;
+    const f16 *xp = p.x + b * p.xsb + hkc * p.xsh + (long long)xrow * p.xsn + m * DM;
+    float x[DM];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) x[k] = (float)xp[k];
+    const int tok = tok0 + t;
+    const int page = tok / p.page_size;
+    const bool tok_ok = valid && tok0 >= 0 && page < p.n_pages_cap;
+    const long long pid = p.page_ids[(long long)(b * p.nh_k + hkc) * p.n_pages_cap + (tok_ok ? page : 0)];
+    // (3) codebook row -> LDS as fp32
+    if ((int)threadIdx.x < C * DM) rows[threadIdx.x] = (float)cv;
+    for (int e = threadIdx.x + kFlushWaves * 64; e < C * DM; e += kFlushWaves * 64) rows[e] = (float)cm[e];
+    // every wave has its lengths in registers before the barrier lets thread 0 take the ticket
+    asm volatile("" :: "s"(tok0), "s"(xrow_start) : "memory");
+    __syncthreads();
+    int ticket = -1;
+    if (f.dev_lengths_w && threadIdx.x == 0)
+        ticket = __hip_atomic_fetch_add(f.dev_lengths_w + b * 4 + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (4) scan this wave's part of the centroids
+    const int cq = (C + parts - 1) / parts;
+    const int c0 = part * cq, c1 = min(c0 + cq, C);
+    float best = INFINITY;
+    int best_c = c0 < C ? c0 : 0;
+    if (active) {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                const float e = x[k] - rows[c * DM + k];
+                const float sq = e * e;
+                acc = (k == 0) ? sq : acc + sq;
+            }
+            best_c = acc < best ? c : best_c;
+            best = fminf(best, acc);
+        }
+    }
+    cand_d[w][lane] = best;
+    cand_c[w][lane] = best_c;
+    __syncthreads();
+    if (active && part == 0 && tok_ok) {
+        // parts in centroid order, strict '<': the lowest index wins exact ties; an empty part left +inf
+        for (int j = 1; j < parts; ++j) {
+            const float dj = cand_d[j * hp + hl][lane];
+            if (dj < best) { best = dj; best_c = cand_c[j * hp + hl][lane]; }
+        }
+        const int off = tok % p.page_size;
+        if (p.layout == MILLION_CODES_KPAGES) p.dst[(pid * p.page_size + off) * p.M + m] = (uint8_t)best_c;
+        else p.dst[(pid * p.M + m) * p.page_size + off] = (uint8_t)best_c;
+    }
+    // (5) the workgroup whose ticket was the last one moves the window: every workgroup had read the lengths by then
+    if (ticket >= 0) {
+        const int total = (int)(gridDim.x * gridDim.y);              // workgroups that read batch item b's lengths
+        if (ticket == total - 1) {
+            int *dl = f.dev_lengths_w + b * 4;
+            const int cap_tok = p.n_pages_cap * p.page_size;
+            int T = dl[0], r = dl[1], st = dl[2];
+            T = T < 0 ? 0 : T;
+            T = T + f.n_flush > cap_tok ? cap_tok : T + f.n_flush;
+            r = r - f.n_flush < 0 ? 0 : r - f.n_flush;
+            st = (unsigned)st < (unsigned)f.rcap ? st : 0;
+            dl[0] = T;
+            dl[1] = r;
+            dl[2] = (st + f.n_flush) % f.rcap;
             __hip_atomic_store(dl + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -230,14 +333,22 @@ __global__ __launch_bounds__(kEncBlock) void pq_flush_kernel(FlushParams f) {
 
 int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, hipStream_t s) {
     if (k.n <= 0 || k.bs * k.nh_k <= 0) return MILLION_OK;
+    if (k.C > 256) { set_error("flush: uint8 codes only (C=%d)", k.C); return MILLION_ERR_SHAPE; }
     FlushParams f;
     f.k = k; f.v = v; f.dev_lengths_w = dev_lengths_w; f.n_flush = k.n; f.rcap = rcap;
-    const dim3 grid((k.n + 63) / 64, 2 * k.M, k.bs * k.nh_k);
+    // kv heads per workgroup: as many as fit its 16 waves, halved while the grid would leave CUs idle
+    const int tblocks = (k.n + 63) / 64;
+    int hp = k.nh_k < kFlushWaves ? k.nh_k : kFlushWaves;
+    const int cus = device_cus();
+    while (hp > 1 && (long long)tblocks * 2 * k.M * ((k.nh_k + hp - 1) / hp) * k.bs < cus) hp = (hp + 1) / 2;
+    f.hp = hp;
+    f.hgroups = (k.nh_k + hp - 1) / hp;
+    const dim3 grid(tblocks, 2 * k.M * f.hgroups, k.bs);
     switch (k.dm) {
-        case 1: hipLaunchKernelGGL((pq_flush_kernel<1>), grid, dim3(kEncBlock), 0, s, f); break;
-        case 2: hipLaunchKernelGGL((pq_flush_kernel<2>), grid, dim3(kEncBlock), 0, s, f); break;
-        case 4: hipLaunchKernelGGL((pq_flush_kernel<4>), grid, dim3(kEncBlock), 0, s, f); break;
-        case 8: hipLaunchKernelGGL((pq_flush_kernel<8>), grid, dim3(kEncBlock), 0, s, f); break;
+        case 1: hipLaunchKernelGGL((pq_flush_kernel<1>), grid, dim3(kFlushWaves * 64), 0, s, f); break;
+        case 2: hipLaunchKernelGGL((pq_flush_kernel<2>), grid, dim3(kFlushWaves * 64), 0, s, f); break;
+        case 4: hipLaunchKernelGGL((pq_flush_kernel<4>), grid, dim3(kFlushWaves * 64), 0, s, f); break;
+        case 8: hipLaunchKernelGGL((pq_flush_kernel<8>), grid, dim3(kFlushWaves * 64), 0, s, f); break;
         default: set_error("flush: d/M=%d unsupported (1,2,4,8)", k.dm); return MILLION_ERR_SHAPE;
     }
     const hipError_t e = hipGetLastError();

@@ -263,6 +263,22 @@ def pool_to_v_rowmajor(pool, ids, T: int):
     return out
 
 
+def pool_to_k_rowmajor(pool, ids, T: int):
+    """Inverse of k_rowmajor_to_pool: pool (n_pool, page_size, M) + page ids -> (bs, nh_k, T, M)."""
+    pool = np.asarray(pool)
+    ids = np.asarray(ids)
+    bs, nhk, n_pages = ids.shape
+    _, ps, M = pool.shape
+    out = np.zeros((bs, nhk, T, M), dtype=np.uint8)
+    for b in range(bs):
+        for h in range(nhk):
+            for p in range(n_pages):
+                t0, t1 = p * ps, min((p + 1) * ps, T)
+                if t1 > t0:
+                    out[b, h, t0:t1, :] = pool[ids[b, h, p], : t1 - t0, :]
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # decode-step attention
 # --------------------------------------------------------------------------------------------------

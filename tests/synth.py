@@ -65,3 +65,6 @@ GOLDEN_ENCODE_U16 = [
 
 # Large encode case: only a SHA-256 of the reference codes and the list of disagreeing positions.
 GOLDEN_ENCODE_BIG = ("cfg1_n4096", 42, 1, 8, 4096, 128, 64, 256)
+
+# BASELINE configs[4]-sized prefill encode (128K tokens, M = 32), one kv head: SHA-256 + flip list in the manifest.
+GOLDEN_ENCODE_128K = ("cfg4_n131072_m32", 43, 1, 1, 131072, 128, 32, 256)

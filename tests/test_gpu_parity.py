@@ -72,12 +72,58 @@ def _run_paged(torch, ops, oracle, c, M, C, ps, k_paged=True, shuffle=True, i64=
 
 # ---------------------------------------------------------------- encode: bit-exact -----------------
 @pytest.mark.parametrize("case", synth.GOLDEN_ENCODE, ids=[c[0] for c in synth.GOLDEN_ENCODE])
-def test_encode_bit_exact_small(case, env, oracle):
+def test_encode_bit_exact_small(case, env, oracle, golden_dir):
     torch, ops = env
     name, seed, bs, nhk, n, d, M, C = case
     c = synth.encode_case(seed, bs, nhk, n, d, M, C)
     codes = ops.pq_encode(torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["cents"]).cuda()).cpu().numpy()
     np.testing.assert_array_equal(codes, oracle.pq_encode(c["X"], c["cents"]))
+    # and directly against the reference's own sa_encode_4d output (cdist form: near-tie flips only)
+    ref = np.load(golden_dir / f"encode_{name}.npz")["codes"]
+    assert np.count_nonzero(codes != ref) <= max(1, codes.size // 100000)
+
+
+@pytest.mark.parametrize("d,M", [(128, 32), (128, 16), (64, 64), (128, 64)], ids=["d128M32", "d128M16", "d64M64", "d128M64"])
+@pytest.mark.parametrize("use_prepared", [True, False], ids=["prepared-f32tab", "raw-f16tab"])
+def test_encode_bulk_kernel_instances(d, M, use_prepared, env, oracle):
+    """The BULK encode kernel (pq_encode_kernel<DM, F32TAB, uint8_t>, taken from 1024 waves on: a prompt-sized call) for
+    every sub-vector width the BASELINE configs use - d_m = 4 (configs[4]: M = 32), 8, 1 and 2 - with the prepared
+    (fp32 image, scalar operands) and the raw fp16 codebook, into all three destinations; n = 4096 tokens x 8 kv heads
+    (the flush-sized LDS kernel serves only the small calls of the other encode tests)."""
+    torch, ops = env
+    from million_amd import _lib as L
+    bs, nhk, n, C, ps = 1, 8, 4096 + 37, 256, 64
+    c = synth.encode_case(3000 + d + M, bs, nhk, n, d, M, C)
+    gold = oracle.pq_encode(c["X"], c["cents"])
+    Xd, cd = torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["cents"]).cuda()
+    out = torch.zeros(bs, nhk, n, M, dtype=torch.uint8, device="cuda")
+    ops.pq_encode_into(Xd, cd, out, use_prepared=use_prepared)
+    np.testing.assert_array_equal(out.cpu().numpy(), gold)
+    n_pages = (n + ps - 1) // ps
+    ids = torch.randperm(bs * nhk * n_pages).to(torch.int32).reshape(bs, nhk, n_pages).cuda()
+    kpool = torch.zeros(bs * nhk * n_pages, ps, M, dtype=torch.uint8, device="cuda")
+    vpool = torch.zeros(bs * nhk * n_pages, M, ps, dtype=torch.uint8, device="cuda")
+    ops.pq_encode_into(Xd, cd, kpool, layout=L.MILLION_CODES_KPAGES, page_ids=ids, page_size=ps, use_prepared=use_prepared)
+    ops.pq_encode_into(Xd, cd, vpool, layout=L.MILLION_CODES_VPAGES, page_ids=ids, page_size=ps, use_prepared=use_prepared)
+    idn = ids.cpu().numpy()
+    np.testing.assert_array_equal(oracle.pool_to_k_rowmajor(kpool.cpu().numpy(), idn, n), gold)
+    np.testing.assert_array_equal(oracle.pool_to_v_rowmajor(vpool.cpu().numpy(), idn, n), gold)
+
+
+def test_encode_128k_m32_prefill_hash(env, oracle, golden_dir):
+    """BASELINE configs[4]'s prefill encode (131072 tokens, M = 32, d_m = 4; one kv head): SHA-256 of the HIP codes ==
+    the hash tools/gen_golden.py computed from the oracle, which tests/test_oracle.py ties to the SHA-256 of the
+    reference's own sa_encode_4d output through the manifest's flip list (3 near ties of 4 194 304 codes)."""
+    torch, ops = env
+    man = json.loads((golden_dir / "manifest.json").read_text())["encode_128k_m32"]
+    name, seed, bs, nhk, n, d, M, C = synth.GOLDEN_ENCODE_128K
+    c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+    codes = ops.pq_encode(torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["cents"]).cuda()).cpu().numpy()
+    assert hashlib.sha256(codes.tobytes()).hexdigest() == man["sha256_direct_oracle_codes"]
+    ref_like = codes.copy()
+    for pos, ref_code in zip(man["diff_positions"], man["diff_reference_codes"]):
+        ref_like[tuple(pos)] = ref_code
+    assert hashlib.sha256(ref_like.tobytes()).hexdigest() == man["sha256_reference_cdist_codes"]
 
 
 def test_encode_bit_exact_cfg1_hash(env, oracle, golden_dir):
@@ -896,6 +942,95 @@ def test_flush_one_launch_equals_separate_encodes(env, oracle):
     for b in range(bs):
         for h in range(nhk):
             np.testing.assert_array_equal(pools[1][0][idn[b, h, T0 // ps]], gold[b, h])
+
+
+@pytest.mark.parametrize("bs,nhk,d,M,C,ps,cap,n", [(1, 8, 128, 64, 256, 64, 128, 64), (1, 32, 128, 64, 256, 64, 128, 64),
+                                                   (2, 3, 128, 32, 256, 64, 256, 128), (1, 5, 64, 16, 128, 32, 128, 32),
+                                                   (3, 1, 128, 16, 256, 64, 128, 64), (1, 20, 64, 64, 256, 128, 512, 128)])
+def test_flush_kernel_head_groups_and_shapes(bs, nhk, d, M, C, ps, cap, n, env, oracle):
+    """The one-launch flush deals kv heads to 16-wave workgroups (hp heads x 16 / hp parts of the centroid range): every
+    grouping the launcher can pick (8 heads -> 2 groups of 4, 32 heads -> 2 passes of 16, 3 / 5 / 20 heads -> idle waves
+    and a short last group, 1 head -> 16 parts), d_m in {1, 2, 4, 8}, C = 128, two token blocks; codes vs the oracle,
+    lengths advanced on the device."""
+    torch, ops = env
+    rs = np.random.RandomState(600 + nhk + M)
+    ck = rs.standard_normal((M, C, d // M)).astype(np.float16)
+    cv = rs.standard_normal((M, C, d // M)).astype(np.float16)
+    kw = rs.standard_normal((bs, nhk, cap, d)).astype(np.float16)
+    vw = rs.standard_normal((bs, nhk, cap, d)).astype(np.float16)
+    n_pages, T0, start = 7, 2 * ps, cap - 9
+    ids = torch.randperm(bs * nhk * n_pages).to(torch.int32).reshape(bs, nhk, n_pages).cuda()
+    kpool = torch.zeros(bs * nhk * n_pages, ps, M, dtype=torch.uint8, device="cuda")
+    vpool = torch.zeros(bs * nhk * n_pages, M, ps, dtype=torch.uint8, device="cuda")
+    dl = torch.tensor([[T0, cap, start, 0]] * bs, dtype=torch.int32, device="cuda")
+    ops.pq_flush(torch.from_numpy(kw).cuda(), torch.from_numpy(vw).cuda(), torch.from_numpy(ck).cuda(),
+                 torch.from_numpy(cv).cuda(), kpool, vpool, ids, n=n, page_size=ps, dev_lengths=dl)
+    torch.cuda.synchronize()
+    assert dl.cpu().tolist() == [[T0 + n, cap - n, (start + n) % cap, 0]] * bs
+    rows = (np.arange(n) + start) % cap
+    gk, gv = oracle.pq_encode(kw[:, :, rows], ck), oracle.pq_encode(vw[:, :, rows], cv)
+    idn = ids.cpu().numpy()
+    np.testing.assert_array_equal(oracle.pool_to_k_rowmajor(kpool.cpu().numpy(), idn, T0 + n)[:, :, T0:], gk)
+    np.testing.assert_array_equal(oracle.pool_to_v_rowmajor(vpool.cpu().numpy(), idn, T0 + n)[:, :, T0:], gv)
+    assert not oracle.pool_to_k_rowmajor(kpool.cpu().numpy(), idn, T0)[:, :, :T0].any()      # nothing written elsewhere
+
+
+def test_flush_device_lengths_are_clamped_not_trusted(env, oracle):
+    """Corrupt device lengths handed to the flush / encode kernels (destination token past the page table or negative,
+    ring start outside the window) must drop stores or fall back to start 0 - never write outside the pools - and the
+    advanced lengths stay inside their ranges."""
+    torch, ops = env
+    from million_amd import _lib as L
+    bs, nhk, d, M, C, ps, cap, n_pages = 4, 2, 128, 64, 256, 64, 128, 3
+    rs = np.random.RandomState(77)
+    ck = torch.from_numpy(rs.standard_normal((M, C, 2)).astype(np.float16)).cuda()
+    kw = rs.standard_normal((bs, nhk, cap, d)).astype(np.float16)
+    kwd = torch.from_numpy(kw).cuda()
+    ids = torch.arange(bs * nhk * n_pages, dtype=torch.int32).reshape(bs, nhk, n_pages).cuda()
+    bad = [[n_pages * ps + 5000, cap, 0, 0], [-64, cap, 0, 0], [ps, cap, cap + 40, 0], [ps, 10, -3, 0]]
+    guard = 4      # guard pages around the pools: must stay zero
+    for which in ("flush", "encode_small", "encode_bulk"):
+        kpool = torch.zeros((bs * nhk * n_pages + 2 * guard), ps, M, dtype=torch.uint8, device="cuda")
+        vpool = torch.zeros((bs * nhk * n_pages + 2 * guard), M, ps, dtype=torch.uint8, device="cuda")
+        kin, vin = kpool[guard:-guard], vpool[guard:-guard]
+        dl = torch.tensor(bad, dtype=torch.int32, device="cuda")
+        if which == "flush":
+            ops.pq_flush(kwd, kwd, ck, ck, kin, vin, ids, n=ps, page_size=ps, dev_lengths=dl)
+        else:
+            nn = ps if which == "encode_small" else cap
+            src = kwd if which == "encode_small" else kwd.repeat(1, 8, 1, 1)[:, :nhk * 8]
+            idw = ids if which == "encode_small" else ids.repeat(1, 8, 1)
+            if which == "encode_bulk":      # 16 kv heads x 128 rows: enough waves for the bulk kernel
+                kin = torch.zeros(bs * nhk * 8 * n_pages, ps, M, dtype=torch.uint8, device="cuda")
+                vin = torch.zeros(bs * nhk * 8 * n_pages, M, ps, dtype=torch.uint8, device="cuda")
+                idw = torch.arange(bs * nhk * 8 * n_pages, dtype=torch.int32).reshape(bs, nhk * 8, n_pages).cuda()
+            kw_ = dict(n=nn, page_ids=idw, page_size=ps, x_row_start=0, x_row_mod=cap, dev_lengths=dl)
+            ops.pq_encode_into(src, ck, kin, layout=L.MILLION_CODES_KPAGES, **kw_)
+            ops.pq_encode_into(src, ck, vin, layout=L.MILLION_CODES_VPAGES, **kw_)
+        torch.cuda.synchronize()
+        kp = kpool.cpu().numpy()
+        assert not kp[:guard].any() and not kp[-guard:].any() and not vpool.cpu().numpy()[:guard].any()
+        kn = kin.cpu().numpy()
+        idn = (ids if which != "encode_bulk" else idw).cpu().numpy()
+        nn = ps if which != "encode_bulk" else cap
+        srcn = kw if which != "encode_bulk" else np.tile(kw, (1, 8, 1, 1))
+        # items 0, 1: destination outside the table / negative -> nothing stored
+        for b in (0, 1):
+            assert not kn[idn[b].ravel()].any(), (which, b)
+        # items 2, 3: ring start outside the window -> rows from start 0, stored at token ps
+        gold = oracle.pq_encode(srcn[:, :, :nn], ck.cpu().numpy())
+        for b in (2, 3):
+            for h in range(idn.shape[1]):
+                if which == "encode_bulk" and nn > ps:      # tokens ps .. ps + 127: pages 1 and 2
+                    got = np.concatenate([kn[idn[b, h, 1]], kn[idn[b, h, 2]]])
+                else:
+                    got = kn[idn[b, h, 1]]
+                np.testing.assert_array_equal(got, gold[b, h], err_msg=f"{which} item {b} head {h}")
+        if which == "flush":
+            out = dl.cpu().numpy()
+            assert (out[:, 3] == 0).all()
+            assert (out[:, 0] >= 0).all() and (out[:, 0] <= n_pages * ps).all()
+            assert (out[:, 1] >= 0).all() and (out[:, 2] >= 0).all() and (out[:, 2] < cap).all()
 
 
 def test_rowmajor_v_shadow_reuse_and_invalidation(env, oracle):

@@ -247,3 +247,34 @@ def test_fvecs_and_centroid_formats(tmp_path):
     torch.save(vc, tmp_path / "cents" / "val_cent_16_8.pq.pt")
     with pytest.raises(ValueError):
         F.load_centroids(tmp_path / "cents", 16, 8)
+
+
+def test_formats_against_reference_written_files(golden_dir):
+    """Files written by the REFERENCE's own writers (tools/gen_golden.py: fvecio.py:35-43 write_fvecs in its default
+    append mode; main_pq.py:222-226 torch `save` of the fp32 centroid tensor), committed as data: million_amd/formats.py
+    must read them back exactly, and its own writer must produce the same bytes."""
+    import hashlib
+    import json
+
+    import numpy as np
+    import torch
+    from million_amd import formats as F
+    man = json.loads((golden_dir / "manifest.json").read_text())["formats"]
+    fv = golden_dir / man["fvecs_file"]
+    assert hashlib.sha256(fv.read_bytes()).hexdigest() == man["fvecs_sha256"]
+    want = np.asarray(man["fvecs_expected"], dtype=np.float32)
+    got = F.read_fvecs(fv)
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, want)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        mine = f"{td}/mine.fvecs"
+        F.write_fvecs(mine, want[:3])
+        F.write_fvecs(mine, want[3:])
+        assert open(mine, "rb").read() == fv.read_bytes()
+    pq = man["pq_pt"]
+    kc, vc = F.load_centroids(golden_dir, pq["M"], pq["nbits"], d=pq["d"], dtype=torch.float32)
+    np.testing.assert_array_equal(kc.numpy(), np.asarray(pq["key"], dtype=np.float32))
+    np.testing.assert_array_equal(vc.numpy(), np.asarray(pq["val"], dtype=np.float32))
+    k16, _ = F.load_centroids(golden_dir, pq["M"], pq["nbits"])      # default: the model dtype the caches take
+    assert k16.dtype == torch.float16 and k16.shape == (4, 4, 2)

@@ -87,6 +87,26 @@ def test_encode_big_hash_and_flip_list(golden_dir, oracle):
     assert hashlib.sha256(ref_like.tobytes()).hexdigest() == man["sha256_reference_cdist_codes"]
 
 
+def test_encode_128k_m32_hash_and_flip_list(golden_dir, oracle):
+    """BASELINE configs[4]-sized prefill encode (131072 tokens, M = 32, one kv head): same pin as encode_big - the
+    oracle's codes, patched at the listed near-tie positions with the reference's values, hash to the SHA-256 of the
+    reference's own sa_encode_4d output (tools/gen_golden.py)."""
+    man = json.loads((golden_dir / "manifest.json").read_text())["encode_128k_m32"]
+    name, seed, bs, nhk, n, d, M, C = synth.GOLDEN_ENCODE_128K
+    assert man["name"] == name and man["n_codes"] == bs * nhk * n * M
+    c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+    codes, gap = oracle.pq_encode_with_gap(c["X"], c["cents"])
+    assert hashlib.sha256(codes.tobytes()).hexdigest() == man["sha256_direct_oracle_codes"]
+    assert man["n_diff_cdist_vs_direct"] == len(man["diff_positions"]) <= max(1, codes.size // 100000)
+    ref_like = codes.copy()
+    for pos, ref_code, own_code, g in zip(man["diff_positions"], man["diff_reference_codes"], man["diff_direct_codes"],
+                                          man["diff_gaps"]):
+        assert codes[tuple(pos)] == own_code != ref_code
+        assert g < 1e-5 and gap[tuple(pos)] == np.float32(g)
+        ref_like[tuple(pos)] = ref_code
+    assert hashlib.sha256(ref_like.tobytes()).hexdigest() == man["sha256_reference_cdist_codes"]
+
+
 @pytest.mark.parametrize("case", synth.GOLDEN_ENCODE_U16, ids=[c[0] for c in synth.GOLDEN_ENCODE_U16])
 def test_encode_u16_oracle_vs_reference_codes(case, golden_dir, oracle):
     """nbits 9..12 -> uint16 codes (nbits2dtype, pq_utils.py:542-552): fixtures are the reference's

@@ -125,6 +125,48 @@ def main():
         "diff_direct_codes": [int(direct[tuple(p)]) for p in diff[:64]],
     }
     print("encode big:", manifest["encode_big"]["n_diff_cdist_vs_direct"], "of", codes.size, "differ")
+
+    # ---- BASELINE configs[4]-sized prefill encode (128K tokens, M = 32, one kv head): hashes + flip list, as above ----
+    (name, seed, bs, nhk, n, d, M, C) = synth.GOLDEN_ENCODE_128K
+    c = synth.encode_case(seed, bs, nhk, n, d, M, C)
+    X, cents = torch.from_numpy(c["X"]).float(), torch.from_numpy(c["cents"]).float()
+    codes = R.sa_encode_4d(X, cents).numpy()      # one call on the whole prompt, as the reference's prefill makes it
+    direct, gap = O.pq_encode_with_gap(c["X"], c["cents"])
+    diff = np.argwhere(direct != codes)
+    manifest["encode_128k_m32"] = {
+        "name": name, "sha256_reference_cdist_codes": hashlib.sha256(codes.tobytes()).hexdigest(),
+        "sha256_direct_oracle_codes": hashlib.sha256(direct.tobytes()).hexdigest(),
+        "n_codes": int(codes.size), "n_diff_cdist_vs_direct": int(diff.shape[0]),
+        "diff_positions": diff.tolist()[:256],
+        "diff_gaps": [float(gap[tuple(p)]) for p in diff[:256]],
+        "diff_reference_codes": [int(codes[tuple(p)]) for p in diff[:256]],
+        "diff_direct_codes": [int(direct[tuple(p)]) for p in diff[:256]],
+    }
+    print("encode 128k m32:", manifest["encode_128k_m32"]["n_diff_cdist_vs_direct"], "of", codes.size, "differ")
+
+    # ---- on-disk formats written BY the reference's own writers (data files) ----
+    # .fvecs: scripts/utils/fvecio.py:35-43 write_fvecs (default append mode: creates, then appends)
+    from scripts.utils import fvecio as RF
+    rs = np.random.RandomState(77)
+    va, vb = rs.standard_normal((3, 5)).astype(np.float32), rs.standard_normal((2, 5)).astype(np.float32)
+    fv = out_dir / "ref_written.fvecs"
+    if fv.exists():
+        fv.unlink()
+    RF.write_fvecs(fv, va)
+    RF.write_fvecs(fv, vb)
+    back = RF.read_fvecs(fv)
+    assert back.shape == (5, 5)
+    # .pq.pt: main_pq.py:222-226 `from torch import save; save(key_cent, cent_root / f'key_cent_{M}_{nbits}.pq.pt')` with
+    # key_cent the fp32 (M, 2**nbits, d/M) tensor train_pq returns (pq_utils.py:586-609; faiss itself is absent here,
+    # so the VALUES are synthetic - the file format is the reference's call)
+    from torch import save
+    kc = torch.from_numpy(rs.standard_normal((4, 4, 2)).astype(np.float32))
+    vc = torch.from_numpy(rs.standard_normal((4, 4, 2)).astype(np.float32))
+    save(kc, out_dir / "key_cent_4_2.pq.pt")
+    save(vc, out_dir / "val_cent_4_2.pq.pt")
+    manifest["formats"] = {"fvecs_file": fv.name, "fvecs_expected": np.concatenate([va, vb]).tolist(),
+                           "fvecs_sha256": hashlib.sha256(fv.read_bytes()).hexdigest(),
+                           "pq_pt": {"M": 4, "nbits": 2, "d": 8, "key": kc.tolist(), "val": vc.tolist()}}
     (out_dir / "manifest.json").write_text(json.dumps(manifest, indent=1))
 
 
