@@ -167,7 +167,8 @@ typedef struct {
 
 size_t million_attn_workspace_bytes(const million_attn_desc *desc);
 /* The workspace must be zeroed once after allocation (million_workspace_init or any memset); every call
- * leaves it ready for the next one. */
+ * leaves it ready for the next one.  Calls of DIFFERENT shapes may share a workspace (sized for the largest) as long as
+ * bs * nh_k <= 2048; a shape with more (b, kv head) pairs needs a workspace of its own. */
 int million_workspace_init(void *workspace, size_t bytes, million_stream_t stream);
 
 int million_pq_decode_attn(const million_attn_desc *desc,

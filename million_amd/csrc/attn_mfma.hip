@@ -510,16 +510,164 @@ __device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&p
     }
 }
 
-// ---- tail shared by the MFMA kernels: merge the waves of the workgroup through LDS (the tables are dead after
-//      the first barrier), publish the split's partial, merge the splits in the last-arriving workgroup ----
+// =====================================================================================================
+// Tail shared by the MFMA kernels (round 3): wave partials -> LDS -> the split's partial -> workspace -> merge.
+//
+// Round 2 handed the split partials over through MEMORY: write-through (sc1) stores, drain, barrier, one returning
+// ticket atomic, barrier, and in the last arriver 64 KiB of sc1 loads by one workgroup - three dependent fabric round
+// trips, 3.4 us of an 18 us launch (profiles/r02_stamps.txt).  Now (protocol measured in isolation by
+// tools/micro/l2_handoff.hip -> profiles/r03_l2_handoff.txt):
+//   * the kernel deals all splits of a (b, kv head) to ONE XCD (workgroup i runs on XCD i % 8).  A plain store is in
+//     that XCD's L2 when its vmcnt retires, and an sc1 load issued on the same XCD is served from there (it bypasses
+//     only the L1): a same-XCD hand-off never leaves the chiplet.  Whether the placement really holds is checked, not
+//     assumed: in its prologue every workgroup MARKS its slot of the (b, kv head)'s census line with its XCC id (one
+//     write-through 4-byte store), and at the start of its tail it reads the line: only if all nsplit slots carry its own
+//     XCC id does it store its partial plain; otherwise (another XCD, or a workgroup that has not started yet)
+//     write-through (sc1), which any XCD can read.  Loads and polls are sc1 in both cases;
+//   * nobody waits for a ticket: the arrival index is taken at the START of the tail (wave 7, which stores nothing; the
+//     round trip hides behind the wave merge); the storing waves drain their stores, and behind the workgroup barrier
+//     they then join the split's FLAG (= generation + 1) is raised; the nm = min(G, nsplit) workgroups whose index is highest are the
+//     mergers: ONE wave of each polls the flags (lane = split, bounded) and merges ONE query head - 16 KiB of loads, wave
+//     reductions by DPP / row swaps, no LDS, no barrier.  Every workgroup a merger waits for has reached its own tail and
+//     waits for nothing, so the polls end under any dispatch order;
+//   * the workgroup with the highest index clears the census line and the counter and advances the generation once its
+//     own poll has seen every flag (all census reads and stores of the launch are behind those flags);
+//   * nsplit = 1: the only workgroup normalises and writes the output itself.
+// =====================================================================================================
+__device__ __forceinline__ unsigned *tail_rec(const AttnParams &p, int bh) { return (unsigned *)p.ws_cnt + (long long)bh * kRecWords; }
+__device__ __forceinline__ unsigned *tail_flags(const AttnParams &p, int bh) { return p.ws_flags + (long long)bh * (2 * kFlagWords); }
+__device__ __forceinline__ unsigned tail_xcc() { return __builtin_amdgcn_s_getreg(6164) & 7u; }      // hwreg(HW_REG_XCC_ID, 0, 4)
+
+// Census mark: thread 0, write-through (every XCD must be able to read it, and no copy may linger dirty in an L2 when the
+// last workgroup clears the line), in a wave-uniform branch of wave 0.  hipcc sizes wave 0's later vmcnt waits as if the
+// store had not been issued, so wave 0's next wait for an OLDER load also waits for this store's acknowledgement: it is
+// placed in the prologue behind the first gathers, where that next wait is ~1 us away, in the wave that reaches the
+// wave-merge barrier 1.6 us early anyway.  The same wave drains it (vmcnt(0)) before this workgroup's flag goes up.
+// (First form of this tail: a returning start-counter atomic, a census atomic and a generation load up here, by all eight
+// waves: 512 same-line memory-side operations per (b, kv head) queued at one channel and launches took 20-25 us; by one
+// lane: the body still ran 1.4 us longer.)
+__device__ __forceinline__ void tail_mark_xcd(const AttnParams &p, int bh, int split, int wave, int lane) {
+    if (wave == 0) {
+        if (lane == 0) __hip_atomic_store(tail_flags(p, bh) + kFlagWords + split, tail_xcc() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The tail's three requests - census line (wave 0, lane = split), arrival index (returning atomic) and generation (thread
+// (kNW-1)*64) - issued ~3 us ahead of the tail, between the last blocks of the streaming loop: under the full code stream a
+// memory round trip takes 2-3 us, more than the wave merge hides (the census read at the start of the tail held barrier B
+// for 0.7 us).  Every lane of every wave issues the three instructions - no branch between two blocks of the pipeline, and
+// no conditional vector-memory operation for hipcc's wait counting - but only the lanes named above address inside the
+// descriptors; the hardware drops out-of-range lanes (loads return 0).
+struct TailReq {
+    int idx;
+    unsigned gen, cen;
+    bool done;      // wave-uniform: false = this wave never passed the early request point (it had no whole round)
+};
+__device__ __forceinline__ void tail_request(const AttnParams &p, int bh, int ns, int wave, int lane, TailReq &t) {
+    constexpr int kOut = 1 << 20;
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)tail_rec(p, bh), 0, kRecWords * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(tail_flags(p, bh) + kFlagWords), 0, kFlagWords * 4, 0x00020000);
+    const bool one = wave == kNW - 1 && lane == 0;
+    t.cen = __builtin_amdgcn_raw_buffer_load_b32(rc, wave == 0 ? (lane < ns ? lane : 0) * 4 : kOut, 0, 16);
+    t.idx = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rr, one ? 2 * 4 : kOut, 0, 0);
+    t.gen = __builtin_amdgcn_raw_buffer_load_b32(rr, one ? 3 * 4 : kOut, 0, 16);
+    t.done = true;
+}
+
+// 16-lane row reductions by DPP (quad swaps, half-row mirror, row mirror), then the four rows by the row swaps
+#define MILLION_DPP(x, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (CTRL), 0xf, 0xf, false))
+__device__ __forceinline__ float wave_max_valu(float x) {
+    x = fmaxf(x, MILLION_DPP(x, 0xB1));      // quad_perm [1,0,3,2]
+    x = fmaxf(x, MILLION_DPP(x, 0x4E));      // quad_perm [2,3,0,1]
+    x = fmaxf(x, MILLION_DPP(x, 0x141));     // row_half_mirror
+    x = fmaxf(x, MILLION_DPP(x, 0x140));     // row_mirror
+    return rows_max(x);
+}
+__device__ __forceinline__ float wave_sum_valu(float x) {
+    x += MILLION_DPP(x, 0xB1);
+    x += MILLION_DPP(x, 0x4E);
+    x += MILLION_DPP(x, 0x141);
+    x += MILLION_DPP(x, 0x140);
+    return rows_sum(x);
+}
+
+// One query head merged by ONE wave: lane (h, q) owns float4 q of the head's 128 outputs for the splits s = h (mod 2).
+__device__ __forceinline__ void tail_merge_head_wave(const AttnParams &p, int b, int hk, int g, int ns, const float *src, int lane) {
+    const int q = lane & 31, h = lane >> 5;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+    // softmax weights of the splits (lane = split)
+    const bool on = lane < ns;
+    const int sl = on ? lane : 0;
+    const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + g) * 4, 0, 16));
+    const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + g) * 4, 0, 16));
+    v4f32 acc = {0.f, 0.f, 0.f, 0.f};
+    float wgt = 0.f;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {      // splits [0, 32), then [32, 64) when there are that many (wave-uniform)
+        if (pass == 1 && ns <= 32) break;
+        v4u v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int slot = 32 * pass + 2 * k + h;
+            const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * 128 + 4 * q) * 4, 0, 16);
+        }
+        if (pass == 0) {
+            const float m0 = on ? m1 : -INFINITY;
+            const float l0 = on ? l1 : 0.f;
+            const float mx = wave_max_valu(m0);
+            const float ms_ = mx > -INFINITY ? mx : 0.f;
+            const float w0 = fast_exp2(m0 - ms_);                           // -inf -> 0
+            const float den = wave_sum_valu(w0 * l0);
+            wgt = den > 0.f ? w0 / den : 0.f;                               // nothing to attend to: 0
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float we = lane_bcast(wgt, 2 * k), wo = lane_bcast(wgt, 2 * k + 1);
+            const float we2 = lane_bcast(wgt, 32 + 2 * k), wo2 = lane_bcast(wgt, 32 + 2 * k + 1);
+            const float w = pass == 0 ? (h ? wo : we) : (h ? wo2 : we2);
+            acc += w * __builtin_bit_cast(v4f32, v[k]);
+        }
+    }
+    // the two halves of the wave hold the even and the odd splits
+    v4f32 tot;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const v2u t = swap32_self(__float_as_uint(acc[c]));      // lower half twice / upper half twice
+        const unsigned t0 = t[0], t1 = t[1];
+        tot[c] = __uint_as_float(t0) + __uint_as_float(t1);
+    }
+    if (lane < 32) {
+        typedef f16 h4 __attribute__((ext_vector_type(4)));
+        const h4 o = {(f16)tot[0], (f16)tot[1], (f16)tot[2], (f16)tot[3]};
+        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * 128 + 4 * q) = o;
+    }
+}
+
 template <int MS = 64>
 __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *smem, int b, int hk, int split, int G, int tid,
-                                                  int lane, int wave, bool dbg_on, v16f32 (&O)[2][2], float m_run, float l_run) {
+                                                  int lane, int wave, bool dbg_on, v16f32 (&O)[2][2], float m_run, float l_run,
+                                                  TailReq &treq) {
 #define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
+    const int ns = p.nslots;
+    const int bh = b * p.nh_k + hk;
+    // LDS words by absolute address (a generic pointer made these FLAT accesses): [1] arrival index, [2] generation,
+    // [3] 1 = every split of this (b, kv head) runs on this XCD
+    typedef volatile __attribute__((address_space(3))) int *lds_int_p;
+    const lds_int_p tl = (lds_int_p)(size_t)kPartOff;
+    // ---- census line / arrival index / generation: requested ~3 us ago by the streaming loop (tail_request); a wave that
+    //      had no whole round asks now ----
+    if (!treq.done) tail_request(p, bh, ns, wave, lane, treq);
+    const int idx_v = treq.idx;
+    const unsigned gen_v = treq.gen, cen_v = treq.cen;
     // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
     l_run = rows_sum(l_run);
     __syncthreads();
     STAMP(4);
+    if (wave == 0) {
+        const bool all_here = __all(cen_v == tail_xcc() + 1u);
+        if (lane == 0) tl[3] = all_here ? 1 : 0;
+    }
     const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
     float *scr_l = (float *)smem;
     float *mine = scr_l + wave * wstride;
@@ -544,8 +692,10 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     }
     __syncthreads();
     // a thread combines the 8 wave partials of 4 consecutive output elements (16-byte LDS reads) and publishes them
-    // straight from registers with one 16-byte sc1 (write-through) store into this split's workspace slot
-    int *flag = (int *)(smem + kPartOff);
+    // straight from registers with one 16-byte store into this split's workspace slot: plain (stays in this XCD's L2)
+    // when the census says every workgroup of this (b, kv head) runs on this XCD, write-through (sc1) otherwise
+    const bool same_xcd = tl[3] != 0;
+    const int nsw = (G * 32 + 63) >> 6;                  // waves that store
     float *dst = slot_ptr(p, b, hk, split);
     {
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, 0x7fffffff, 0x00020000);
@@ -571,16 +721,78 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                 acc += f * vw[w];
                 lsum = fmaf(f, lw[w], lsum);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 16 /* sc1 */);
-            if ((q & 31) == 0) {
-                st_agent(dst + G * 128 + g, Mx);
-                st_agent(dst + G * 128 + G + g, lsum);
+            if (ns == 1) {      // the only split of this (b, kv head): normalise and write the output (nothing to attend to: 0)
+                const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+                typedef f16 h4 __attribute__((ext_vector_type(4)));
+                const h4 o = {(f16)(acc[0] * inv), (f16)(acc[1] * inv), (f16)(acc[2] * inv), (f16)(acc[3] * inv)};
+                *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk)) * 128 + 4 * q) = o;
+            } else if (same_xcd) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 0);
+                if ((q & 31) == 0) {
+                    dst[G * 128 + g] = Mx;
+                    dst[G * 128 + G + g] = lsum;
+                }
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 16 /* sc1 */);
+                if ((q & 31) == 0) {
+                    st_agent(dst + G * 128 + g, Mx);
+                    st_agent(dst + G * 128 + G + g, lsum);
+                }
             }
         }
     }
     STAMP(5);
-    ticket_and_merge(p, b, hk, scr_l, flag);      // its first barrier also fences the scratch reads above from the reuse below
-    MILLION_STAMP(p, 6);   // wave scratch is dead after the barrier above
+    if (wave == kNW - 1 && lane == 0) { tl[1] = idx_v; tl[2] = (int)gen_v; }      // the index and the generation have arrived
+    // a storing wave's partial is out of the CU (in L2, or in memory) when its vmcnt retires; the flag is raised behind the
+    // barrier every storing wave then joins (cdna_hip_programming.md Guideline 16, R1)
+    if (ns > 1 && wave < nsw) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // wave scratch is dead; index and generation are visible to every wave
+    MILLION_STAMP(p, 10);
+    const int idx = tl[1];
+    const unsigned want = (unsigned)tl[2] + 1u;
+    if (ns > 1 && tid == 0) {
+        __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
+        if (same_xcd) __builtin_amdgcn_raw_buffer_store_b32(want, rf, split * 4, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(want, rf, split * 4, 0, 16 /* sc1 */);
+    }
+    const int nm = G < ns ? G : ns;                      // mergers: the workgroups that reached their tail last
+    const int j = idx - (ns - nm);
+    if (j >= 0 && ns > 1) {
+        // ---- merger: wave w merges head j + w * nm; it polls the flags itself (lane = split): its loads follow its own match ----
+        const int g = j + wave * nm;
+        if (g < G) {
+            __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
+            const int fo = (lane < ns ? lane : 0) * 4;
+            for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
+                const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                if (__all(f == want)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            MILLION_STAMP(p, 11);
+            tail_merge_head_wave(p, b, hk, g, ns, p.ws_part + (long long)bh * ns * p.slot_floats, lane);
+        }
+    }
+    if (idx == ns - 1 && tid == 0) {
+        // the workgroup that arrived last: its wave 0 has seen every flag of this launch (or ns == 1), so every workgroup of
+        // this (b, kv head) has read the census line and the generation and stored its partial
+        unsigned *rec = tail_rec(p, bh);
+        __hip_atomic_store(rec + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // fused append with device-resident lengths: every workgroup of batch b has read its lengths once all nh_k
+        // heads have got this far; the last of them advances r
+        if (p.k_new && p.dev_lengths_w) {
+            const int t2 = __hip_atomic_fetch_add(p.ws_cnt2 + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t2 == p.nh_k - 1) {
+                __hip_atomic_store(p.ws_cnt2 + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.dev_lengths_w[b * 4 + 1] += 1;
+            }
+        }
+    }
+    if (idx == ns - 1 && wave == 0) {      // census line back to zero (write-through: the next launch may run anywhere)
+        __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(tail_flags(p, bh) + kFlagWords), 0, kFlagWords * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(0u, rc, lane * 4, 0, 16 /* sc1 */);
+    }
+    MILLION_STAMP(p, 6);
     if (dbg_on && lane < kStampSlots) {              // copy this wave's LDS stamps out (slots it wrote)
         const unsigned long long v =
             *(volatile __attribute__((address_space(3))) unsigned long long *)(size_t)(kStampOff + (wave * kStampSlots + lane) * 8);
@@ -692,6 +904,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     STAMP(8);
     __syncthreads();     // no LDS-DMA in flight: lgkmcnt(0) + s_barrier, the code bytes stay in flight
     STAMP(1);
+    tail_mark_xcd(p, bh, split, wave, lane);      // this split's slot of the XCD census (tail)
 
     // ---- everything else is requested BETWEEN the score units of the first group (the K bytes and the K
     //      codebook are there; a wave that first issued all its remaining loads would sit in a blocked issue
@@ -823,7 +1036,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #undef ISSUE_AFTER_UNIT
 #undef UNIT_T
     STAMP(3);
-    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run);
+    TailReq treq;
+    treq.done = false;
+    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run, treq);
 #undef STAMP
 }
 
@@ -1300,6 +1515,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         VALUE_ALONE(SL)                                                                                            \
     }
     const int n_whole = n_mine >> 2, n_rem = n_mine & 3;      // whole rounds of four units + up to three more
+    TailReq treq;
+    treq.idx = 0; treq.gen = 0; treq.cen = 0; treq.done = false;
     {
         // prologue: the 8 score stages of round 0 (masked out when the wave has no whole round: its units are all
         // handled as single units below); round 2 is requested in between
@@ -1307,6 +1524,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             KG(0, 0);
             KG(0, 1);
+            tail_mark_xcd(p, bh, split, wave, lane);      // this split's slot of the XCD census (see there for the placement)
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 KM(st);
@@ -1342,6 +1560,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             }
             BLOCK(0, j)
             BLOCK(1, j + 1)
+            tail_request(p, bh, p.nslots, wave, lane, treq);      // ~3 us ahead of the tail (see there)
             BLOCK(2, j + 2)
             STAMP(19);
             VALUE_ALONE(3)
@@ -1364,7 +1583,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef UNIT_REQ_K
 #undef UNIT_REQ_V
     STAMP(3);
-    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l);
+    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l, treq);
 #undef STAMP
 }
 

@@ -11,7 +11,15 @@ typedef _Float16 f16;
 
 constexpr int kMaxSplits = 64;      // code splits per (b, hk); workspace is sized for this
 constexpr int kMaxG = 8;            // q heads per kv head handled by one workgroup
-constexpr int kCntBytes = 1024;     // counter block at the start of the workspace (multiple of 16)
+constexpr int kCntBytes = 1024;     // granule of the counter / flag blocks at the start of the workspace
+// Workspace head: one 128-byte record per (b, kv head), then one int per batch item (second-level ticket), then
+// 2 x kFlagWords words per (b, kv head) (split flags, XCD census line), then the split partials.  Record words (u32):
+//   [0..1]  u64 arrival ticket of the round-2 hand-off (ticket_and_merge below: tile and scalar kernels)
+//   [2]     arrival counter } L2 hand-off of the MFMA kernels (attn_mfma.hip, "Tail"): index of a workgroup among those
+//   [3]     generation      } of its (b, kv head) in the order they reach their tails; flags of launch n carry generation + 1
+// Every word is back at its resting value (0; generation advanced) when a launch ends.
+constexpr int kRecWords = 32;
+constexpr int kFlagWords = 64;      // one flag per split (the MFMA kernels use at most kMaxSplits = 64 slots)
 
 // Kernel parameter block (passed by value).
 struct AttnParams {
@@ -37,7 +45,8 @@ struct AttnParams {
     int *ws_cnt2;          // per-batch second-level ticket
     f16 *out;
     float *ws_part;
-    unsigned long long *ws_cnt;   // per (b, kv head): arrivals of this launch, one byte per XCD (ticket_and_merge)
+    unsigned long long *ws_cnt;   // records of kRecWords u32 per (b, kv head), see above
+    unsigned *ws_flags;           // 2 * kFlagWords per (b, kv head): split flags, then the XCD census line
     const int *__restrict__ dev_lengths;
     int bs, nh, nh_k, G, d, M, C, dm;   // G: query heads of a kv head served by THIS launch (<= kMaxG)
     int Gt, g0;                         // nh / nh_k, and the first of them this launch serves (query-head groups > kMaxG: several launches)
@@ -48,7 +57,7 @@ struct AttnParams {
     int nsplit;      // code splits per (b, hk)
     int nslots;      // partial slots per (b, hk)
     int split_len;   // tokens per split
-    int slot_floats; // floats per partial slot = G*d + 2*G (padded to 4)
+    int slot_floats; // floats per partial slot = G*d + 2*G, padded to whole 128-byte lines (no line is shared by two slots)
     float scale_log2e;
     unsigned long long *dbg;   // diagnostic stamp buffer (million_debug_set_stamp_buffer), normally null
 };
@@ -165,9 +174,9 @@ __device__ __forceinline__ float ld_agent(const float *p) {
 // Returns false (nothing done) for shapes it does not cover.
 typedef unsigned mv4u __attribute__((ext_vector_type(4)));
 typedef float mv4f __attribute__((ext_vector_type(4)));
-// AUX = cache-policy bits of the loads of handed-off bytes: 16 (sc1, agent scope: the bytes may have been written on
-// another XCD, whose L2 is not coherent with ours - every load goes to memory, ~1.7 us) or 1 (sc0: coherent at THIS
-// XCD's L2) when the tickets say every producer ran on the merger's own XCD (ticket_and_merge).
+// AUX = cache-policy bits of the loads of handed-off bytes: 16 (sc1, agent scope).  (Round 2 switched to sc0 loads when
+// the ticket said every producer had run on the merger's XCD; an sc0 load may be served by the CU's L1, which nothing
+// refreshes - tools/micro/l2_handoff.hip shows polls with sc0 loads never seeing a later store - so that path is gone.)
 template <int G_, int AUX>
 __device__ __forceinline__ void merge_vec4(const AttnParams &p, int b, int hk, const float *src, int ns, float *scratch) {
     constexpr int kThreads = 512, kD = 128;
@@ -247,19 +256,12 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        // One 64-bit counter per (b, kv head), one byte per XCD (<= 65 arrivals): the sum of the bytes is the ticket, and
-        // "only my byte is non-zero" tells the last arriver that every partial was written through ITS OWN L2.
-        const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-        const unsigned long long mine = 1ull << (8 * xcc);
-        const unsigned long long now = __hip_atomic_fetch_add(p.ws_cnt + bh, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
-        unsigned long long s = (now & 0x00ff00ff00ff00ffull) + ((now >> 8) & 0x00ff00ff00ff00ffull);
-        s = (s & 0x0000ffff0000ffffull) + ((s >> 16) & 0x0000ffff0000ffffull);
-        const int arrived = (int)((s + (s >> 32)) & 0xffffffffull);
-        *flag_lds = arrived != p.nslots ? 0 : (now == ((unsigned long long)p.nslots << (8 * xcc)) ? 2 : 1);
+        const unsigned long long now = __hip_atomic_fetch_add(p.ws_cnt + (long long)bh * (kRecWords / 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        *flag_lds = now == (unsigned long long)p.nslots ? 1 : 0;
     }
     __syncthreads();
     MILLION_STAMP(p, 10);
-    const int arrival = *flag_lds;      // 0 = not the last, 1 = last, 2 = last and every producer ran on this XCD
+    const int arrival = *flag_lds;      // 1 = this workgroup arrived last
     if (!arrival) return;
 
     // ---- last arriver: merge all slots of (b, hk); every load of handed-off bytes is an sc1 load ----
@@ -272,17 +274,10 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
     if (nthr == 512 && d == 128 && ns <= 32 && (G == 1 || G == 2 || G == 4 || G == 8)) {      // workgroup-uniform
         MILLION_STAMP(p, 11);
-        if (arrival == 2) {               // every producer on this XCD: loads coherent at our L2
-            if (G == 4) merge_vec4<4, 1>(p, b, hk, src, ns, scratch);
-            else if (G == 8) merge_vec4<8, 1>(p, b, hk, src, ns, scratch);
-            else if (G == 2) merge_vec4<2, 1>(p, b, hk, src, ns, scratch);
-            else merge_vec4<1, 1>(p, b, hk, src, ns, scratch);
-        } else {
-            if (G == 4) merge_vec4<4, 16>(p, b, hk, src, ns, scratch);
-            else if (G == 8) merge_vec4<8, 16>(p, b, hk, src, ns, scratch);
-            else if (G == 2) merge_vec4<2, 16>(p, b, hk, src, ns, scratch);
-            else merge_vec4<1, 16>(p, b, hk, src, ns, scratch);
-        }
+        if (G == 4) merge_vec4<4, 16>(p, b, hk, src, ns, scratch);
+        else if (G == 8) merge_vec4<8, 16>(p, b, hk, src, ns, scratch);
+        else if (G == 2) merge_vec4<2, 16>(p, b, hk, src, ns, scratch);
+        else merge_vec4<1, 16>(p, b, hk, src, ns, scratch);
         goto merged;
     }
     {
@@ -344,7 +339,7 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     }
 merged:
     if (tid == 0) {
-        __hip_atomic_store(p.ws_cnt + bh, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.ws_cnt + (long long)bh * (kRecWords / 2), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // fused append with device-resident lengths: every workgroup of batch b has read its lengths once
         // all nh_k heads have been merged; the last merger advances r
         if (p.k_new && p.dev_lengths_w) {

@@ -131,11 +131,25 @@ __global__ __launch_bounds__(256) void codes_transpose_kernel(const uint8_t *__r
     }
 }
 
+// Workspace layout: [records: P x 128 B | second-level tickets: P x int] [flags + census: P x 2 x kFlagWords x 4 B] [partials], with
+// P = max(kHeadPairs, bs * nh_k): the head does not move with the shape, so calls of different shapes may share one
+// (once-zeroed) workspace - every call leaves the head at rest and nobody ever reads another call's partials.  (Round 2
+// sized the counter block by bs * nh_k: a larger shape found an earlier call's partials where it expected zeros.)  A
+// shape with more than kHeadPairs (b, kv head) pairs needs a workspace of its own (million_hip.h).
+constexpr size_t kHeadPairs = 2048;
+static size_t head_pairs(int bs, int nh_k) { const size_t n = (size_t)bs * nh_k; return n > kHeadPairs ? n : kHeadPairs; }
+static size_t slot_floats_for(int G, int d) { return (size_t)(G * d + 2 * G + 31) / 32 * 32; }      // whole 128-byte lines
+static size_t attn_cnt_bytes(int bs, int nh_k) {
+    const size_t cnt = head_pairs(bs, nh_k) * (kRecWords * sizeof(unsigned) + sizeof(int));
+    return (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
+}
+static size_t attn_flag_bytes(int bs, int nh_k) {
+    const size_t f = head_pairs(bs, nh_k) * 2 * kFlagWords * sizeof(unsigned);      // flags + XCD census line
+    return (f + kCntBytes - 1) / kCntBytes * kCntBytes;
+}
 static size_t attn_partial_bytes(int bs, int nh_k, int G, int d) {
-    const size_t slot = (size_t)(G * d + 2 * G + 3) / 4 * 4;
-    size_t cnt = (size_t)bs * nh_k * sizeof(unsigned long long) + (size_t)bs * sizeof(int);      // tickets per (b, hk) + per b
-    cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
-    size_t b = cnt + (size_t)bs * nh_k * (kMaxSplits + 1) * slot * sizeof(float);
+    const size_t b = attn_cnt_bytes(bs, nh_k) + attn_flag_bytes(bs, nh_k) +
+                     (size_t)bs * nh_k * (kMaxSplits + 1) * slot_floats_for(G, d) * sizeof(float);
     return (b + 255) / 256 * 256;
 }
 
@@ -172,7 +186,7 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     }
     p.dev_lengths = desc->dev_lengths;
     p.scale_log2e = 1.4426950408889634f / sqrtf((float)p.d);
-    p.slot_floats = (p.G * p.d + 2 * p.G + 3) / 4 * 4;
+    p.slot_floats = (int)slot_floats_for(p.G, p.d);
     return MILLION_OK;
 }
 
@@ -379,12 +393,11 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.k_new = (const f16 *)k_new; p.v_new = (const f16 *)v_new;
     p.k_res_w = (f16 *)k_resid; p.v_res_w = (f16 *)v_resid;
     p.dev_lengths_w = (int *)desc->dev_lengths;
-    size_t cnt = (size_t)p.bs * p.nh_k * sizeof(unsigned long long) + (size_t)p.bs * sizeof(int);
-    cnt = (cnt + kCntBytes - 1) / kCntBytes * kCntBytes;
     p.ws_cnt = (unsigned long long *)workspace;
-    p.ws_cnt2 = (int *)(p.ws_cnt + p.bs * p.nh_k);
+    p.ws_cnt2 = (int *)((unsigned *)workspace + head_pairs(p.bs, p.nh_k) * kRecWords);
+    p.ws_flags = (unsigned *)((char *)workspace + attn_cnt_bytes(p.bs, p.nh_k));
     p.dbg = g_dbg;
-    p.ws_part = (float *)((char *)workspace + cnt);
+    p.ws_part = (float *)((char *)workspace + attn_cnt_bytes(p.bs, p.nh_k) + attn_flag_bytes(p.bs, p.nh_k));
     // The fast kernels want V in transposed pages: the reference's 10-arg row-major layout is transposed into scratch
     // pages first (once per call, whatever the number of query-head groups below).
     AttnParams pl = p;
@@ -407,7 +420,7 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
         AttnParams pg = pl;
         pg.g0 = g0;
         pg.G = p.Gt - g0 < kMaxG ? p.Gt - g0 : kMaxG;
-        pg.slot_floats = (pg.G * pg.d + 2 * pg.G + 3) / 4 * 4;
+        pg.slot_floats = (int)slot_floats_for(pg.G, pg.d);
         if (g0 > 0 && pg.k_new) {
             pg.k_new = pg.v_new = nullptr;
             if (!pg.dev_lengths) pg.r += 1;

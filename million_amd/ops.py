@@ -221,7 +221,10 @@ def _v_pages_of(v_codes: torch.Tensor, n_tokens: int) -> torch.Tensor:
 def attn_workspace(desc: L.AttnDesc, device: torch.device) -> torch.Tensor:
     lib = L.load()
     need = lib.million_attn_workspace_bytes(ctypes.byref(desc))
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    # one workspace per (device, stream) serves every shape (its head does not move with the shape, million_hip.h);
+    # shapes with more than 2048 (b, kv head) pairs get one of their own
+    pairs = desc.bs * desc.nh_k
+    key = (device.index, torch.cuda.current_stream().cuda_stream, pairs if pairs > 2048 else 0)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < need:
         # zeroed once; every call leaves it ready.  Grown with headroom: the row-major path keeps a

@@ -30,12 +30,15 @@ __device__ __forceinline__ unsigned payload_word(unsigned epoch, int g, int s, i
     return (epoch * 2654435761u) ^ (unsigned)(g * 7919 + s * 104729 + i * 31);
 }
 
-template <int ST, int LD>
+// ELECT: 0 = the last ticket merges (first poll nearly always succeeds), 1 = the FIRST ticket merges (long polling: do
+// repeated polls see later stores?).  MIXED: 1 = groups of consecutive ids (every group spans all 8 XCDs).
+// NMERGE: the last NMERGE tickets each check a 1/NMERGE share of every slot (the per-head mergers of the attention tail).
+template <int ST, int LD, int ELECT = 0, int MIXED = 0, int NMERGE = 1>
 __global__ __launch_bounds__(512) void handoff(unsigned *part, unsigned *flags, unsigned *tick, unsigned long long *stamps,
                                                unsigned *report, unsigned epoch, int spin_bound) {
     extern __shared__ char smem[];
     int *flag_lds = (int *)smem;
-    const int id = blockIdx.x, g = id % NG, s = id / NG;
+    const int id = blockIdx.x, g = MIXED ? id / NS : id % NG, s = MIXED ? id % NS : id / NG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // pseudo-random skew, 0 .. ~1.5 us
     unsigned h = (unsigned)id * 2246822519u + epoch * 3266489917u;
@@ -59,12 +62,14 @@ __global__ __launch_bounds__(512) void handoff(unsigned *part, unsigned *flags, 
             stamps[id * 4 + 0] = __builtin_amdgcn_s_memrealtime();
             __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)(flags + g * FLAG_STRIDE), 0, 0x7fffffff, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(epoch, rf, s * 4, 0, ST);
-            *flag_lds = my_ticket == NS - 1;
+            *flag_lds = ELECT ? (my_ticket == 0 ? 1 : 0) : ((int)my_ticket >= NS - NMERGE ? (int)my_ticket - (NS - NMERGE) + 1 : 0);
         }
     }
     __syncthreads();
     if (!*flag_lds) return;
     // ---- merger ----
+    const int share = *flag_lds - 1;
+    if (share < 0 || share >= NMERGE) return;
     __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)(flags + g * FLAG_STRIDE), 0, 0x7fffffff, 0x00020000);
     int spins = 0;
     bool ok = false;
@@ -78,15 +83,16 @@ __global__ __launch_bounds__(512) void handoff(unsigned *part, unsigned *flags, 
     if (tid == 0) stamps[id * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(part + (size_t)g * NS * SLOT_WORDS), 0, 0x7fffffff, 0x00020000);
     unsigned bad = 0;
-    v4u v[8];
+    constexpr int KL = 8 / NMERGE, QS = 128 / NMERGE;      // float4 per slot in a share
+    v4u v[KL];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {      // 32 slots x 128 float4 = 4096 float4 over 512 threads
-        const int q = k * 512 + tid, sl = q >> 7, i0 = (q & 127) * 4;
+    for (int k = 0; k < KL; ++k) {      // 32 slots x (128 / NMERGE) float4 over 512 threads
+        const int q = k * 512 + tid, sl = q / QS, i0 = (share * QS + q % QS) * 4;
         v[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, (sl * SLOT_WORDS + i0) * 4, 0, LD);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int q = k * 512 + tid, sl = q >> 7, i0 = (q & 127) * 4;
+    for (int k = 0; k < KL; ++k) {
+        const int q = k * 512 + tid, sl = q / QS, i0 = (share * QS + q % QS) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) bad += v[k][j] != payload_word(epoch, g, sl, i0 + j);
     }
@@ -95,27 +101,31 @@ __global__ __launch_bounds__(512) void handoff(unsigned *part, unsigned *flags, 
     __syncthreads();
     if (tid == 0) {
         stamps[id * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-        report[g * 4 + 1] = ok ? 0u : 1u;        // timeout
-        report[g * 4 + 2] = (unsigned)id;        // who merged
-        report[g * 4 + 3] = (unsigned)spins;
-        __hip_atomic_store(tick + g * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) atomicAdd(report + g * 4 + 1, 1u);      // timeout
+        if (ELECT || my_ticket == NS - 1) {
+            report[g * 4 + 2] = (unsigned)id;            // whose stamps the host reads
+            report[g * 4 + 3] = (unsigned)spins;
+        }
+        if (my_ticket == NS - 1 && !ELECT) __hip_atomic_store(tick + g * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int ST, int LD>
+template <int ST, int LD, int ELECT = 0, int MIXED = 0, int NMERGE = 1>
 void run(const char *name, unsigned *part, unsigned *flags, unsigned *tick, unsigned long long *stamps, unsigned *report,
          int launches, unsigned &epoch) {
-    auto k = handoff<ST, LD>;
+    auto k = handoff<ST, LD, ELECT, MIXED, NMERGE>;
     const int lds = 130 * 1024;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     std::vector<unsigned long long> hs(NS * NG * 4);
     std::vector<unsigned> hr(NG * 4);
     std::vector<double> lat_poll, lat_done;
     long long stale = 0, timeouts = 0, mixed = 0, spins = 0;
+    CK(hipMemset(tick, 0, NG * 32 * 4));      // a run that elects the FIRST ticket leaves the counters at NS
     for (int it = 0; it < launches; ++it) {
         ++epoch;
         CK(hipMemset(report, 0, NG * 4 * sizeof(unsigned)));
         CK(hipMemset(stamps, 0, NS * NG * 4 * sizeof(unsigned long long)));
+        if (ELECT) CK(hipMemset(tick, 0, NG * 32 * 4));
         hipLaunchKernelGGL(k, dim3(NS * NG), dim3(512), lds, 0, part, flags, tick, stamps, report, epoch, 20000);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -128,9 +138,9 @@ void run(const char *name, unsigned *part, unsigned *flags, unsigned *tick, unsi
             unsigned long long last_flag = 0;
             bool mix = false;
             for (int s = 0; s < NS; ++s) {
-                const int id = s * NG + g;
+                const int id = MIXED ? g * NS + s : s * NG + g;
                 last_flag = std::max(last_flag, hs[id * 4 + 0]);
-                mix |= hs[id * 4 + 3] != hs[g * 4 + 3];
+                mix |= hs[id * 4 + 3] != hs[(MIXED ? g * NS : g) * 4 + 3];
             }
             mixed += mix;
             if (it >= 4) {
@@ -169,5 +179,17 @@ int main() {
     run<2, 2>("store nt / load nt", part, flags, tick, stamps, report, L, epoch);
     run<1, 16>("store sc0 / load sc1", part, flags, tick, stamps, report, L, epoch);
     run<16, 16>("store sc1 / load sc1 (again)", part, flags, tick, stamps, report, L, epoch);
+    printf("-- four mergers (the last four tickets), a quarter of every slot each --\n");
+    run<16, 16, 0, 0, 4>("sc1 / sc1, 4 mergers", part, flags, tick, stamps, report, L, epoch);
+    run<0, 16, 0, 0, 4>("plain / sc1, 4 mergers", part, flags, tick, stamps, report, L, epoch);
+    printf("-- the FIRST ticket merges: long polling --\n");
+    run<0, 16, 1>("plain / sc1, first merges", part, flags, tick, stamps, report, L, epoch);
+    run<0, 2, 1>("plain / nt, first merges", part, flags, tick, stamps, report, L, epoch);
+    run<0, 1, 1>("plain / sc0, first merges", part, flags, tick, stamps, report, 20, epoch);
+    run<16, 16, 1>("sc1 / sc1, first merges", part, flags, tick, stamps, report, L, epoch);
+    printf("-- groups spread over all 8 XCDs --\n");
+    run<16, 16, 0, 1>("MIXED sc1 / sc1", part, flags, tick, stamps, report, L, epoch);
+    run<16, 16, 1, 1>("MIXED sc1 / sc1, first merges", part, flags, tick, stamps, report, L, epoch);
+    run<0, 16, 0, 1>("MIXED plain / sc1 (must fail)", part, flags, tick, stamps, report, 20, epoch);
     return 0;
 }

@@ -75,7 +75,7 @@ if args.grouped:     # labels of the grouped kernel (attn_mfma_kernel)
              (19, "  issue: V bytes units 2-3"), (20, "score unit 2"), (21, "  issue: V codebook"), (22, "score unit 3"),
              (24, "residual tile scores, softmax update"), (12, "append store, V codebook -> LDS"),
              (13, "barrier 2"), (3, "residual tile values, value pass (+ later groups)"),
-             (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
+             (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial stored, drained, barrier"), (6, "flag raised; end (mergers: poll + merge of one head)")]
 else:                # labels of the streaming kernel (attn_stream_kernel)
     order = [(0, "kernel start"), (7, "requested: page ids, q, both codebooks, residual tile, units 0-1"),
              (8, "codebooks written to LDS"), (1, "barrier (codebooks)"), (2, "residual tile done"),
@@ -83,7 +83,7 @@ else:                # labels of the streaming kernel (attn_stream_kernel)
              (17, "first whole round of 4 blocks (splits of >= 8 units per wave)"),
              (19, "blocks of the last whole round"),
              (3, "values of the last unit of the round (+ single units beyond the whole rounds)"),
-             (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial published + ticket"), (6, "end (last arriver: merge done)")]
+             (4, "wave-merge barrier"), (5, "wave merge done"), (10, "partial stored, drained, barrier"), (6, "flag raised; end (mergers: poll + merge of one head)")]
 s = last
 t0 = s[:, :, 0].min()
 print(f"workgroups {s.shape[0]}; kernel span (first start -> last end) per launch [us]: {[round(float(x), 2) for x in spans]}")
@@ -111,7 +111,7 @@ if args.raw:
             print(f"   stamp {sid:2d} @{m_:6.2f} ({lo:5.2f}..{hi:5.2f}) [{n}]")
 la = s[:, 0, :][s[:, 0, 11] != 0]
 if la.shape[0]:
-    print("  last arrivers (%d): ticket -> weights ready %.2f | -> out written %.2f us" % (
+    print("  mergers (%d): barrier -> every flag seen %.2f | -> head merged, out written %.2f us" % (
         la.shape[0], ((la[:, 11] - la[:, 10]) / 100.0).mean(), ((la[:, 6] - la[:, 11]) / 100.0).mean()))
 e = (s[:, 0, 6] - t0) / 100.0
 print("  end relative to first start: mean %.2f max %.2f us" % (e.mean(), e.max()))
