@@ -527,7 +527,7 @@ __device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&p
 //   * nobody waits for a ticket: the arrival index is taken at the START of the tail (wave 7, which stores nothing; the
 //     round trip hides behind the wave merge); the storing waves drain their stores, and behind the workgroup barrier
 //     they then join the split's FLAG (= generation + 1) is raised; the nm = min(G, nsplit) workgroups whose index is highest are the
-//     mergers: ONE wave of each polls the flags (lane = split, bounded) and merges ONE query head - 16 KiB of loads, wave
+//     mergers: four waves of each poll the flags (lane = split, bounded) and merge ONE query head - 16 KiB of loads, wave
 //     reductions by DPP / row swaps, no LDS, no barrier.  Every workgroup a merger waits for has reached its own tail and
 //     waits for nothing, so the polls end under any dispatch order;
 //   * the workgroup with the highest index clears the census line and the counter and advances the generation once its
@@ -591,56 +591,53 @@ __device__ __forceinline__ float wave_sum_valu(float x) {
     return rows_sum(x);
 }
 
-// One query head merged by ONE wave: lane (h, q) owns float4 q of the head's 128 outputs for the splits s = h (mod 2).
-__device__ __forceinline__ void tail_merge_head_wave(const AttnParams &p, int b, int hk, int g, int ns, const float *src, int lane) {
-    const int q = lane & 31, h = lane >> 5;
+// One query head is merged by FOUR waves: wave part (0..3) owns outputs [32 part, 32 part + 32) of the head; its lane
+// (h, q8) owns float4 q8 of those for the splits s = h (mod 8): ns / 8 16-byte loads per lane (one wave per head: 16 per
+// lane and 1.2 us from "every flag seen" to "output written"), the eight split subsets are summed with DPP / row swaps.
+__device__ __forceinline__ void tail_merge_head_part(const AttnParams &p, int b, int hk, int g, int part, int ns, const float *src,
+                                                     int lane) {
+    const int q8 = lane & 7, h = lane >> 3;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
     // softmax weights of the splits (lane = split)
     const bool on = lane < ns;
     const int sl = on ? lane : 0;
     const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + g) * 4, 0, 16));
     const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + g) * 4, 0, 16));
-    v4f32 acc = {0.f, 0.f, 0.f, 0.f};
-    float wgt = 0.f;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {      // splits [0, 32), then [32, 64) when there are that many (wave-uniform)
-        if (pass == 1 && ns <= 32) break;
-        v4u v[16];
+    v4u v[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int slot = 32 * pass + 2 * k + h;
-            const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
-            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * 128 + 4 * q) * 4, 0, 16);
-        }
-        if (pass == 0) {
-            const float m0 = on ? m1 : -INFINITY;
-            const float l0 = on ? l1 : 0.f;
-            const float mx = wave_max_valu(m0);
-            const float ms_ = mx > -INFINITY ? mx : 0.f;
-            const float w0 = fast_exp2(m0 - ms_);                           // -inf -> 0
-            const float den = wave_sum_valu(w0 * l0);
-            wgt = den > 0.f ? w0 / den : 0.f;                               // nothing to attend to: 0
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float we = lane_bcast(wgt, 2 * k), wo = lane_bcast(wgt, 2 * k + 1);
-            const float we2 = lane_bcast(wgt, 32 + 2 * k), wo2 = lane_bcast(wgt, 32 + 2 * k + 1);
-            const float w = pass == 0 ? (h ? wo : we) : (h ? wo2 : we2);
-            acc += w * __builtin_bit_cast(v4f32, v[k]);
-        }
+    for (int k = 0; k < 8; ++k) {
+        const int slot = 8 * k + h;
+        const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
+        if (k < 4 || ns > 32)                                          // wave-uniform: the second half only for more than 32 splits
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * 128 + 32 * part + 4 * q8) * 4, 0, 16);
+        else
+            v[k] = v4u{0, 0, 0, 0};
     }
-    // the two halves of the wave hold the even and the odd splits
-    v4f32 tot;
+    const float m0 = on ? m1 : -INFINITY;
+    const float l0 = on ? l1 : 0.f;
+    const float mx = wave_max_valu(m0);
+    const float ms_ = mx > -INFINITY ? mx : 0.f;
+    const float w0 = fast_exp2(m0 - ms_);                               // -inf -> 0 (lanes >= ns: 0)
+    // unnormalised sum first, 1 / (sum of w l) at the end: the denominator's reduction runs beside the accumulation
+    v4f32 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (8 * k + h), __builtin_bit_cast(int, w0)));
+        acc += w * __builtin_bit_cast(v4f32, v[k]);
+    }
+    const float den = wave_sum_valu(w0 * l0);
+    const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;    // nothing to attend to: 0
+    // sum over the eight split subsets: lanes l, l ^ 8 (same 16-lane row), then the four rows
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const v2u t = swap32_self(__float_as_uint(acc[c]));      // lower half twice / upper half twice
-        const unsigned t0 = t[0], t1 = t[1];
-        tot[c] = __uint_as_float(t0) + __uint_as_float(t1);
+        float x = acc[c];
+        x += MILLION_DPP(x, 0x128);      // row_ror:8
+        acc[c] = rows_sum(x) * inv;
     }
-    if (lane < 32) {
+    if (lane < 8) {
         typedef f16 h4 __attribute__((ext_vector_type(4)));
-        const h4 o = {(f16)tot[0], (f16)tot[1], (f16)tot[2], (f16)tot[3]};
-        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * 128 + 4 * q) = o;
+        const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * 128 + 32 * part + 4 * q8) = o;
     }
 }
 
@@ -755,21 +752,29 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         if (same_xcd) __builtin_amdgcn_raw_buffer_store_b32(want, rf, split * 4, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b32(want, rf, split * 4, 0, 16 /* sc1 */);
     }
+    if (p.dbg && tid == 0)      // diagnostics: slot 12 = 1 + "stored plain (every split on this XCD)", slot 13 = 1 + arrival index
+        { unsigned long long *d_ = p.dbg + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves * kStampSlots; d_[12] = 1 + (same_xcd ? 1 : 0); d_[13] = 1 + idx; }
     const int nm = G < ns ? G : ns;                      // mergers: the workgroups that reached their tail last
     const int j = idx - (ns - nm);
     if (j >= 0 && ns > 1) {
-        // ---- merger: wave w merges head j + w * nm; it polls the flags itself (lane = split): its loads follow its own match ----
-        const int g = j + wave * nm;
-        if (g < G) {
-            __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
-            const int fo = (lane < ns ? lane : 0) * 4;
-            for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
-                const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
-                if (__all(f == want)) break;
-                __builtin_amdgcn_s_sleep(1);
+        // ---- merger: four waves per head (waves 0-3: head j, waves 4-7: head j + nm, then j + 2 nm ...); every merging wave
+        //      polls the flags itself (lane = split): its loads follow its own match ----
+        // (A dry run of the merge during the poll wait does warm the instruction cache - the merge proper falls from 1.25
+        // to 0.8 us - but takes 1.2 us itself, more than the 0.55 us a merger waits for the last flags: 17.4 vs 16.7 us.)
+        bool polled = false;
+        for (int g = j + (wave >> 2) * nm; g < G; g += 2 * nm) {
+            if (!polled) {
+                __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
+                const int fo = (lane < ns ? lane : 0) * 4;
+                for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
+                    const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                    if (__all(f == want)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                polled = true;
+                MILLION_STAMP(p, 11);
             }
-            MILLION_STAMP(p, 11);
-            tail_merge_head_wave(p, b, hk, g, ns, p.ws_part + (long long)bh * ns * p.slot_floats, lane);
+            tail_merge_head_part(p, b, hk, g, wave & 3, ns, p.ws_part + (long long)bh * ns * p.slot_floats, lane);
         }
     }
     if (idx == ns - 1 && tid == 0) {
@@ -788,7 +793,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
             }
         }
     }
-    if (idx == ns - 1 && wave == 0) {      // census line back to zero (write-through: the next launch may run anywhere)
+    if (idx == ns - 1 && wave == 0) {      // census line back to zero, behind this wave's own poll (write-through: the next launch may run anywhere)
         __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(tail_flags(p, bh) + kFlagWords), 0, kFlagWords * 4, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b32(0u, rc, lane * 4, 0, 16 /* sc1 */);
     }
@@ -1560,8 +1565,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             }
             BLOCK(0, j)
             BLOCK(1, j + 1)
-            tail_request(p, bh, p.nslots, wave, lane, treq);      // ~3 us ahead of the tail (see there)
             BLOCK(2, j + 2)
+            tail_request(p, bh, p.nslots, wave, lane, treq);      // ~3 us ahead of the point where the tail needs the answers
             STAMP(19);
             VALUE_ALONE(3)
         }

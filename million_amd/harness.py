@@ -327,3 +327,120 @@ class GraphedPQDecoder:
         self.graphs["flush" if cache.next_step_flushes() else "plain"].replay()
         cache.note_replayed_step()
         return self.tokens
+
+
+def speedtest(*, ctx=32768, decode=10, niter=5, bs=1, model="llama31_8b", layers=None,
+              backends=("hf_baseline", "static_fp16", "pq_eager", "pq_graph"), prefill=True, breakdown=False,
+              ttft_iters=2, device=None, log=None, deadline=None):
+    """The reference's speed test (scripts/benchmarks/speedtest.py:85-117) on a Llama-shaped random-weight model: one
+    warm-up generation, then `niter` timed ones of `decode` tokens; every generated token is handed to the host (the
+    reference's streamer), the wall-clock interval between consecutive tokens is recorded, TPOT = sum(intervals[1:]) /
+    (decode - 1) (:104) and, with `prefill`, TTFT = the prompt pass of `ctx` random tokens up to the first token on the
+    host (:105) - through the model's q/k/v projections, RoPE, the backend's prefill (PQ: bulk encode of every layer into
+    pages + causal attention on the fp16 prompt, pq_utils.py:222-260) and MLP.  Without `prefill` the caches are filled
+    synthetically at `ctx` tokens.  `breakdown` adds the reference's per-section timers (Timer.py; speedtest.py:110-117).
+    `deadline` (time.time() value): a backend that would start after it is skipped and says so.
+    Returns a dict: config, one record per backend, speed-ups of the PQ backends over the two fp16 baselines."""
+    device = device or torch.device("cuda", 0)
+    shape = getattr(LlamaShape, model)()
+    if layers:
+        shape.n_layers = layers
+    net = LlamaShapeDecoder(shape, device)
+    dl = decode
+    max_new = (niter + 2) * dl + 16
+    results = {"config": {"model": model, "ctx": ctx, "decoding_length": dl, "niter": niter, "bs": bs,
+                          "layers": shape.n_layers, "weights": "random fp16", "prompt": "random ids" if prefill else "synthetic cache fill",
+                          "tpot": "speedtest.py:104 definition: mean inter-token interval, the first (prompt) interval excluded"}}
+
+    def run_generation(step_fn):
+        """dl tokens; returns the inter-token wall-clock intervals in ms (host receives every token)."""
+        torch.cuda.synchronize()
+        ivals, t_prev = [], time.perf_counter()
+        for _ in range(dl):
+            step_fn().cpu()                    # streamer.put(token) -> host
+            t = time.perf_counter()
+            ivals.append((t - t_prev) * 1e3)
+            t_prev = t
+        return ivals
+
+    def measure(step_fn):
+        run_generation(step_fn)                # warm-up generation (speedtest.py:92)
+        tp = [sum(iv[1:]) / (dl - 1) for iv in (run_generation(step_fn) for _ in range(niter))]
+        return sum(tp) / len(tp)
+
+    def make_backend(name, filled):
+        if name == "hf_baseline":
+            return HFBaselineCache(shape, bs, ctx if filled else 0, device)
+        if name == "static_fp16":
+            return StaticFP16Cache(shape, bs, ctx, max_new, device)
+        if name in ("pq_eager", "pq_graph"):
+            return PQBackend(shape, bs, ctx, max_new, device, synthetic_fill=filled)
+        raise ValueError(f"unknown backend {name}")
+
+    prompt = torch.randint(0, shape.vocab, (bs, ctx), device=device) if prefill else None
+    for name in backends:
+        if deadline is not None and time.time() > deadline:
+            results[name] = {"skipped": "time cap of the caller reached"}
+            continue
+        torch.cuda.empty_cache()
+        tokens = torch.zeros(bs, dtype=torch.long, device=device)
+        pos = torch.full((bs,), ctx, dtype=torch.long, device=device)
+        rec = {}
+        be = None
+        if prefill and name != "static_fp16":      # (the preallocated baseline has no prompt pass of its own)
+            ttft = []
+            for it in range(ttft_iters + 1):       # first one is the warm-up (speedtest.py:92)
+                be = None
+                torch.cuda.empty_cache()
+                be = make_backend(name, filled=False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                first = net.prefill(prompt, be)
+                first.cpu()                        # the first token reaches the host: intervals[0]
+                if it:
+                    ttft.append((time.perf_counter() - t0) * 1e3)
+            rec["ttft_ms"] = round(sum(ttft) / len(ttft), 2)
+            tokens.copy_(first)
+        else:
+            be = make_backend(name, filled=True)
+
+        def eager_step():
+            nxt = net.step(tokens, pos, be)
+            tokens.copy_(nxt)
+            pos.add_(1)
+            return tokens
+
+        if breakdown and name != "pq_graph":       # one generation with the section timers on (eager only)
+            tm = SectionTimers()
+            net.timers = be.timers = tm
+            for _ in range(dl):
+                eager_step().cpu()
+            net.timers = be.timers = NO_TIMERS
+            rec["breakdown_times_s"] = {k: round(v, 5) for k, v in sorted(tm.seconds.items())}
+            rec["breakdown_calls"] = dict(sorted(tm.calls.items()))
+
+        graphed = None
+        if name != "pq_graph":
+            step_fn = eager_step
+        else:
+            graphed = GraphedPQDecoder(net, be, tokens, pos)
+            step_fn = graphed.step
+        tp = measure(step_fn)
+        rec.update({"tpot_ms": round(tp, 4), "tokens_per_s": round(bs * 1e3 / tp, 2)})
+        results[name] = rec
+        if log:
+            log(f"{name} {rec}")
+        del be, step_fn, graphed
+
+    base = results.get("hf_baseline", {}).get("tpot_ms")
+    stat = results.get("static_fp16", {}).get("tpot_ms")
+    for k in ("pq_eager", "pq_graph"):
+        if k in results and "tpot_ms" in results[k]:
+            if base:
+                results[k]["speedup_vs_hf_baseline"] = round(base / results[k]["tpot_ms"], 3)
+            if stat:
+                results[k]["speedup_vs_static_fp16"] = round(stat / results[k]["tpot_ms"], 3)
+            bt = results.get("hf_baseline", {}).get("ttft_ms")
+            if bt and "ttft_ms" in results[k]:
+                results[k]["ttft_vs_hf_baseline"] = round(results[k]["ttft_ms"] / bt, 3)
+    return results

@@ -109,6 +109,9 @@ if args.raw:
         print(f"--- raw stamps, {name}: id @mean (min..max) [waves]")
         for m_, sid, lo, hi, n in sorted(rows):
             print(f"   stamp {sid:2d} @{m_:6.2f} ({lo:5.2f}..{hi:5.2f}) [{n}]")
+if (s[:, 0, 12] != 0).any():
+    print("  workgroups that stored their partial plain (census: every split on their XCD): %d of %d; arrival indices seen: %s" % (
+        int((s[:, 0, 12] == 2).sum()), s.shape[0], sorted(set((s[:, 0, 13] - 1).tolist()))[:6]))
 la = s[:, 0, :][s[:, 0, 11] != 0]
 if la.shape[0]:
     print("  mergers (%d): barrier -> every flag seen %.2f | -> head merged, out written %.2f us" % (
