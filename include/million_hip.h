@@ -214,6 +214,31 @@ int million_attn_kernel_kind(const million_attn_desc *desc);
 void million_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------
+ * Prompt (prefill) attention on fp16 K/V.
+ * Replaces: scaled_dot_product_attention(q, repeat_kv(k), repeat_kv(v), is_causal=True) of the reference's prompt pass
+ * (scripts/utils/pq_utils.py:249-260 DynamicPQCache.prefill, scripts/utils/paged_pq_utils.py:216-320
+ * PagedPQCache.prefill; baseline: scripts/modeldb/models/modeling_llama.py:403-443) - GQA without materialising
+ * repeat_kv: the nh / nh_k query heads of a kv head share the K/V tiles of one workgroup.
+ *   out[b,h,i,:] = softmax_{j <= q_pos0 + i (causal), j < n_kv}( q[b,h,i,:] . k[b,hk,j,:] / sqrt(d) ) v[b,hk,j,:],  hk = h / (nh/nh_k)
+ * fp16 in / out, fp32 scores, online softmax and accumulation; d = 128.  causal = 0: every key (j < n_kv).
+ * torch's is_causal=True with q_len == kv_len is q_pos0 = 0; a prompt chunk behind n_past cached fp16 rows is q_pos0 = n_past. */
+typedef struct {
+    uint32_t struct_size;         /* = sizeof(million_prefill_desc) */
+    int32_t bs, nh, nh_k, d;
+    int32_t n_q, n_kv;            /* query rows, key/value rows */
+    int32_t q_pos0;               /* position of query row 0 among the keys */
+    int32_t causal;
+    int64_t q_stride_b, q_stride_h, q_stride_n;   /* fp16 elements; the d elements of a row are contiguous; multiples of 8 */
+    int64_t k_stride_b, k_stride_h, k_stride_n;
+    int64_t v_stride_b, v_stride_h, v_stride_n;
+    int64_t o_stride_b, o_stride_h, o_stride_n;
+} million_prefill_desc;
+
+int million_prefill_attn(const million_prefill_desc *desc, const void *q /* (bs, nh, n_q, d) */,
+                         const void *k /* (bs, nh_k, n_kv, d) */, const void *v, void *out /* (bs, nh, n_q, d) */,
+                         million_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Residual-window append.
  * Replaces: the two slice-assign copies of DynamicPQCache.decoding (pq_utils.py:304-312) /
  * PagedPQCache.decoding_with_pages (paged_pq_utils.py:377-380).

@@ -38,6 +38,15 @@ class AttnDesc(ctypes.Structure):
                 ("dev_lengths", c_vp)]
 
 
+class PrefillDesc(ctypes.Structure):
+    _fields_ = [("struct_size", c_u32), ("bs", c_i32), ("nh", c_i32), ("nh_k", c_i32), ("d", c_i32),
+                ("n_q", c_i32), ("n_kv", c_i32), ("q_pos0", c_i32), ("causal", c_i32),
+                ("q_stride_b", c_i64), ("q_stride_h", c_i64), ("q_stride_n", c_i64),
+                ("k_stride_b", c_i64), ("k_stride_h", c_i64), ("k_stride_n", c_i64),
+                ("v_stride_b", c_i64), ("v_stride_h", c_i64), ("v_stride_n", c_i64),
+                ("o_stride_b", c_i64), ("o_stride_h", c_i64), ("o_stride_n", c_i64)]
+
+
 # every symbol include/million_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "million_version": (c_i32, []),
@@ -55,6 +64,7 @@ SYMBOLS = {
     "million_pq_decode_attn_append": (c_i32, [ctypes.POINTER(AttnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                               c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "million_attn_kernel_kind": (c_i32, [ctypes.POINTER(AttnDesc)]),
+    "million_prefill_attn": (c_i32, [ctypes.POINTER(PrefillDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "million_set_force_generic": (None, [c_i32]),
     "million_debug_set_stamp_buffer": (None, [c_vp]),
     "million_debug_rows_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp]),

@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmillion_hip.so"
-SOURCES = ["million_api.hip", "encode.hip", "attn_generic.hip", "attn_tile.hip", "attn_mfma.hip"]
+SOURCES = ["million_api.hip", "encode.hip", "attn_generic.hip", "attn_tile.hip", "attn_mfma.hip", "prefill.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value"]
 
 

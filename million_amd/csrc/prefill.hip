@@ -1,0 +1,295 @@
+// prefill.hip — causal prompt attention on fp16 K/V (flash-style, MFMA), gfx950.
+//
+// Replaces: the scaled_dot_product_attention(q, repeat_kv(k), repeat_kv(v), is_causal=True) of the reference's prompt
+// pass (scripts/utils/pq_utils.py:249-260 DynamicPQCache.prefill; scripts/utils/paged_pq_utils.py:216-320
+// PagedPQCache.prefill) - without materialising repeat_kv: the G = nh / nh_k query heads of a kv head are served by the
+// SAME workgroup, so a K/V tile is fetched once per kv head and q block, not once per query head.
+//
+//   out[b, h, i, :] = softmax_j<=q_pos0+i( q[b,h,i,:] . k[b,hk,j,:] / sqrt(d) ) v[b,hk,j,:],   hk = h / G
+//
+// Design
+//   * workgroup = 8 waves = HPW query heads of one kv head x (256 / HPW) query rows; a wave owns 32 query rows of one head.
+//     HPW = the largest of {8, 4, 2, 1} dividing G.  Linear block id -> kv head fastest (8 kv heads = 8 XCDs: every
+//     workgroup that reads a kv head's K/V runs on one XCD, next to its L2), heaviest (last) query blocks first.
+//   * K/V tiles of 64 keys go global -> registers -> LDS, issued one tile ahead (registers filled while the current tile
+//     is computed, written to the other LDS buffer afterwards: one barrier per tile); LDS image of a [64][128] fp16 tile:
+//     off(row, 16-byte chunk ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))): conflict-free both for
+//     the row reads (ds_read_b128, K as the A operand) and for the transposed reads (ds_read_b64_tr_b16, V^T as the A
+//     operand) - cdna_hip_programming.md T10 "one image for row reads AND transposed reads", image (b).
+//   * everything is computed TRANSPOSED so that a query row lives on a lane: S^T = K Q^T (A = K rows from LDS, B = Q^T
+//     from registers, v_mfma_f32_32x32x16_f16): lane (q, h) holds 16 of a 32-key tile's scores of query q; softmax is
+//     in-lane plus ONE half-wave exchange; P^T, converted pairwise to fp16, IS the B operand of O^T += V^T P^T (the
+//     accumulator's row index is the next product's reduction index: no lane movement, no LDS), and the running rescale
+//     of O^T is lane-local.  fp32 online softmax in the exp2 domain, fp32 accumulation, fp16 output.
+//   * causal: a workgroup walks the key tiles up to its last query row's diagonal; a wave skips tiles wholly above its own
+//     rows and masks only the tiles its diagonal crosses.
+//
+// Roofline: MFMA (2.5 PFLOP/s dense fp16).  FLOPs = 4 d nh (number of unmasked (i, j) pairs).  Per 64-key tile a wave
+// issues 32 MFMAs (32 cycles each) and reads 32 KiB of LDS (K and V^T fragments are re-read by each of the 8 waves: 256
+// B/clk/CU at the MFMA rate, i.e. the LDS ceiling equals the MFMA ceiling in this 8 x 32-row decomposition).
+#include "common.h"
+
+namespace million {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned pv4u __attribute__((ext_vector_type(4)));
+typedef short pv4s __attribute__((__vector_size__(4 * sizeof(short))));
+
+struct PrefillParams {
+    const f16 *q, *k, *v;
+    f16 *out;
+    int bs, nh, nh_k, G, d;
+    int n_q, n_kv, q_pos0, causal;
+    long long q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn;      // strides in elements; d contiguous
+    int hpw;            // query heads per workgroup (1, 2, 4, 8)
+    int n_qb;           // query blocks per head (of 256 / hpw rows)
+    float scale_log2e;
+};
+
+constexpr int kPW = 8;            // waves
+constexpr int kKV = 64;           // keys per tile
+constexpr int kTileBytes = kKV * 256;      // one [64][128] fp16 tile
+
+__device__ __forceinline__ unsigned pf_off(int row, int ch) {
+    return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+typedef __attribute__((address_space(3))) pv4u *lds_v4u_p;
+typedef __attribute__((address_space(3))) pv4s *lds_v4s_p;
+
+// D = 128 only (the Llama head size of every BASELINE config).
+__global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams p) {
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];      // [2 buffers][K tile | V tile]
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_smem != 0u) __builtin_trap();      // absolute LDS addressing below
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    // ---- which rows ----
+    int id = blockIdx.x;
+    const int hk = id % p.nh_k;
+    id /= p.nh_k;
+    const int n_hg = p.G / p.hpw;
+    const int hg = id % n_hg;
+    id /= n_hg;
+    const int qb = p.n_qb - 1 - id % p.n_qb;      // heaviest query blocks first
+    const int b = id / p.n_qb;
+    const int wph = kPW / p.hpw;                  // waves per head
+    const int QB = wph * 32;                      // query rows per head in this workgroup
+    const int g = hg * p.hpw + wave / wph;        // query head within the kv head's group
+    const int head = hk * p.G + g;
+    const int q_lo = qb * QB + (wave % wph) * 32; // first query row of this wave
+    const int q_row = q_lo + r32;                 // this lane's query row
+    const int q_pos = p.q_pos0 + q_row;           // its position among the keys (causal: keys <= q_pos)
+
+    // ---- Q^T fragments: B operand, lane (q, h): Q[q][16 s + 8 h .. + 8] ----
+    v8h qf[8];
+    {
+        const int qr = q_row < p.n_q ? q_row : p.n_q - 1;
+        const f16 *qp = p.q + b * p.q_sb + head * p.q_sh + (long long)qr * p.q_sn + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = *(const v8h *)(qp + 16 * s);
+    }
+    // ---- key tiles of this workgroup / of this wave ----
+    const int wg_q_hi = qb * QB + QB - 1 < p.n_q - 1 ? qb * QB + QB - 1 : p.n_q - 1;      // last query row of the workgroup
+    int kv_end_wg = p.causal ? p.q_pos0 + wg_q_hi + 1 : p.n_kv;
+    kv_end_wg = kv_end_wg < p.n_kv ? kv_end_wg : p.n_kv;
+    const int nt = kv_end_wg > 0 ? (kv_end_wg + kKV - 1) / kKV : 0;
+    const int w_pos_lo = p.q_pos0 + q_lo, w_pos_hi = p.q_pos0 + q_lo + 31;                // positions of this wave's rows
+    const bool wave_live = q_lo < p.n_q;                                                   // wave-uniform
+
+    // ---- staging: thread -> two 16-byte chunks of the K tile and two of the V tile ----
+    const f16 *kbase = p.k + b * p.k_sb + hk * p.k_sh;
+    const f16 *vbase = p.v + b * p.v_sb + hk * p.v_sh;
+    pv4u kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 512 * i, row = c >> 4, ch = c & 15;
+            int kvr = t * kKV + row;
+            kvr = kvr < p.n_kv ? kvr : p.n_kv - 1;      // clamped: rows past the end are masked below
+            kreg[i] = *(const pv4u *)(kbase + (long long)kvr * p.k_sn + 8 * ch);
+            vreg[i] = *(const pv4u *)(vbase + (long long)kvr * p.v_sn + 8 * ch);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 512 * i, row = c >> 4, ch = c & 15;
+            const unsigned o = 2u * kTileBytes * buf + pf_off(row, ch);
+            *(lds_v4u_p)(size_t)o = kreg[i];
+            *(lds_v4u_p)(size_t)(o + kTileBytes) = vreg[i];
+        }
+    };
+
+    v16f O[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[i][j] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;      // m in the scaled exp2 domain
+    const float c = p.scale_log2e;
+
+    if (nt > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        load_tile(t + 1 < nt ? t + 1 : t);      // next tile's bytes fly during this tile's products (the last one re-reads itself)
+        const int kv0 = t * kKV;
+        const bool tile_live = wave_live && (!p.causal || kv0 <= w_pos_hi);      // wave-uniform
+        if (tile_live) {
+            const unsigned kb = 2u * kTileBytes * buf, vb = kb + kTileBytes;
+            // ---- S^T = K Q^T: two 32-key x 32-query tiles ----
+            v16f S0, S1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { S0[j] = 0.f; S1[j] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const v8h a0 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off(r32, 2 * s + hh)));
+                const v8h a1 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off(32 + r32, 2 * s + hh)));
+                S0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[s], S0, 0, 0, 0);
+                S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[s], S1, 0, 0, 0);
+            }
+            // ---- mask (only where the diagonal or the end of the keys crosses this tile), scale, online softmax ----
+            float sc[32];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { sc[j] = S0[j]; sc[16 + j] = S1[j]; }
+            const bool need_mask = (p.causal && kv0 + kKV - 1 > w_pos_lo) || kv0 + kKV > p.n_kv;      // wave-uniform
+            if (need_mask) {
+                const int lim = p.causal ? (q_pos < p.n_kv - 1 ? q_pos : p.n_kv - 1) : p.n_kv - 1;     // last key this row attends to
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int kv = kv0 + 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh;
+                    sc[j] = kv <= lim ? sc[j] : -INFINITY;
+                }
+            }
+            float mx = sc[0];
+#pragma unroll
+            for (int j = 1; j < 32; ++j) mx = fmaxf(mx, sc[j]);
+            {
+                const v2u ex = swap32_self(__float_as_uint(mx));      // both halves of the wave: the same query rows
+                const unsigned e0 = ex[0], e1 = ex[1];
+                mx = fmaxf(__uint_as_float(e0), __uint_as_float(e1));
+            }
+            const float m_new = fmaxf(m_run, mx * c);
+            const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+            if (__any(m_new > m_run && m_run > -INFINITY)) {      // some row's maximum moved: rescale (lane-local: a row is a lane)
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) O[i][j] *= alpha;
+                l_run *= alpha;
+            }
+            m_run = m_new;
+            float ls = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                sc[j] = __builtin_amdgcn_exp2f(fmaf(sc[j], c, -m_safe));
+                ls += sc[j];
+            }
+            l_run += ls;
+            // ---- O^T += V^T P^T: P^T registers 8 ks .. 8 ks + 7 of a score tile are k-step ks of the B operand ----
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                    unsigned pw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const h2v t2 = {(f16)sc[16 * jt + 8 * ks + 2 * e], (f16)sc[16 * jt + 8 * ks + 2 * e + 1]};
+                        pw[e] = __builtin_bit_cast(unsigned, t2);
+                    }
+                    const pv4u pwv = {pw[0], pw[1], pw[2], pw[3]};
+                    const v8h pb = __builtin_bit_cast(v8h, pwv);
+                    // A = V^T: element e of lane half h is key 32 jt + 16 ks + 8 (e >> 2) + 4 h + (e & 3), row = value dim
+                    const int kvr0 = 32 * jt + 16 * ks + 4 * hh;
+                    const int qd = (lane >> 2) & 3, pp = lane & 3, g16 = (lane >> 4) & 1;      // lane 4 qd + pp of its 16-lane group
+#pragma unroll
+                    for (int blk = 0; blk < 4; ++blk) {
+                        const int chn = 4 * blk + 2 * g16 + (pp >> 1);
+                        const pv4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off(kvr0 + qd, chn) + 8 * (pp & 1)));
+                        const pv4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off(kvr0 + 8 + qd, chn) + 8 * (pp & 1)));
+                        typedef short v8s __attribute__((ext_vector_type(8)));
+                        const v8s av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        O[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, av), pb, O[blk], 0, 0, 0);
+                    }
+                }
+        }
+        // the other buffer was last read in iteration t - 1; every wave has passed that iteration's barrier
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- normalise and store: lane (q, h) holds dims 32 blk + 8 i + 4 h + (0..3) of its row ----
+    {
+        const v2u ex = swap32_self(__float_as_uint(l_run));
+        const unsigned e0 = ex[0], e1 = ex[1];
+        l_run = __uint_as_float(e0) + __uint_as_float(e1);
+    }
+    if (wave_live && q_row < p.n_q) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        f16 *op = p.out + b * p.o_sb + head * p.o_sh + (long long)q_row * p.o_sn + 4 * hh;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                typedef f16 h4 __attribute__((ext_vector_type(4)));
+                const h4 o = {(f16)(O[blk][4 * i] * inv), (f16)(O[blk][4 * i + 1] * inv), (f16)(O[blk][4 * i + 2] * inv),
+                              (f16)(O[blk][4 * i + 3] * inv)};
+                *(h4 *)(op + 32 * blk + 8 * i) = o;
+            }
+    }
+}
+
+int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
+    PrefillParams p = p_in;
+    int hpw = 1;
+    for (int c = 8; c >= 1; c >>= 1)
+        if (p.G % c == 0) { hpw = c; break; }
+    p.hpw = hpw;
+    const int QB = (kPW / hpw) * 32;
+    p.n_qb = (p.n_q + QB - 1) / QB;
+    const long long blocks = (long long)p.bs * p.nh_k * (p.G / hpw) * p.n_qb;
+    if (blocks <= 0) return MILLION_OK;
+    if (blocks > 0x7fffffffLL) { set_error("prefill: %lld workgroups", blocks); return MILLION_ERR_SHAPE; }
+    const int lds = 4 * kTileBytes;      // two buffers of (K tile, V tile)
+    if (device_once(3)) (void)hipFuncSetAttribute((const void *)prefill_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(prefill_attn_kernel, dim3((unsigned)blocks), dim3(kPW * 64), lds, s, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("prefill launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
+    return MILLION_OK;
+}
+
+}  // namespace million
+
+using namespace million;
+
+extern "C" int million_prefill_attn(const million_prefill_desc *desc, const void *q, const void *k, const void *v, void *out,
+                                    million_stream_t stream) {
+    if (!desc || desc->struct_size != sizeof(million_prefill_desc)) { set_error("prefill: bad desc / struct_size"); return MILLION_ERR_ARG; }
+    if (!q || !k || !v || !out) { set_error("prefill: null pointer"); return MILLION_ERR_ARG; }
+    PrefillParams p;
+    p.q = (const f16 *)q; p.k = (const f16 *)k; p.v = (const f16 *)v; p.out = (f16 *)out;
+    p.bs = desc->bs; p.nh = desc->nh; p.nh_k = desc->nh_k; p.d = desc->d;
+    p.n_q = desc->n_q; p.n_kv = desc->n_kv; p.q_pos0 = desc->q_pos0; p.causal = desc->causal != 0;
+    if (p.bs <= 0 || p.nh <= 0 || p.nh_k <= 0 || p.nh % p.nh_k) { set_error("prefill: bs=%d nh=%d nh_k=%d", p.bs, p.nh, p.nh_k); return MILLION_ERR_SHAPE; }
+    if (p.d != 128) { set_error("prefill: d=%d (128 only)", p.d); return MILLION_ERR_SHAPE; }
+    if (p.n_q < 0 || p.n_kv < 0 || p.q_pos0 < 0) { set_error("prefill: n_q=%d n_kv=%d q_pos0=%d", p.n_q, p.n_kv, p.q_pos0); return MILLION_ERR_ARG; }
+    if (p.n_q == 0) return MILLION_OK;
+    if (p.n_kv == 0) { set_error("prefill: no keys (n_kv = 0) for %d query rows", p.n_q); return MILLION_ERR_ARG; }
+    p.G = p.nh / p.nh_k;
+    p.q_sb = desc->q_stride_b; p.q_sh = desc->q_stride_h; p.q_sn = desc->q_stride_n;
+    p.k_sb = desc->k_stride_b; p.k_sh = desc->k_stride_h; p.k_sn = desc->k_stride_n;
+    p.v_sb = desc->v_stride_b; p.v_sh = desc->v_stride_h; p.v_sn = desc->v_stride_n;
+    p.o_sb = desc->o_stride_b; p.o_sh = desc->o_stride_h; p.o_sn = desc->o_stride_n;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) { set_error("prefill: every pointer must be 16-byte aligned"); return MILLION_ERR_ALIGN; }
+    if ((p.q_sb | p.q_sh | p.q_sn | p.k_sb | p.k_sh | p.k_sn | p.v_sb | p.v_sh | p.v_sn | p.o_sb | p.o_sh | p.o_sn) & 7) {
+        set_error("prefill: strides must be multiples of 8 elements (16-byte rows)");
+        return MILLION_ERR_ALIGN;
+    }
+    p.scale_log2e = 1.4426950408889634f / sqrtf((float)p.d);
+    return launch_prefill(p, (hipStream_t)stream);
+}

@@ -351,6 +351,40 @@ def pq_decode_attn(q: torch.Tensor, k_codes: torch.Tensor, v_codes: torch.Tensor
     return out
 
 
+def prefill_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bool = True, q_pos0: int = 0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Prompt attention on fp16 K/V (million_prefill_attn): q (bs, nh, n_q, d), k / v (bs, nh_k, n_kv, d) -> (bs, nh, n_q, d).
+    Replaces scaled_dot_product_attention(q, repeat_kv(k), repeat_kv(v), is_causal=True) of the reference's prompt pass
+    (pq_utils.py:249-260) without materialising repeat_kv.  Row strides are free (transposed (bs, n, h, d) projections are
+    fine), the d elements of a row must be contiguous."""
+    _need_cuda(q, k, v, out)
+    if q.dtype != torch.float16 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise RuntimeError("prefill_attn: q, k, v must be fp16")
+    if q.dim() != 4 or k.dim() != 4 or k.shape != v.shape or q.shape[0] != k.shape[0] or q.shape[3] != k.shape[3]:
+        raise RuntimeError(f"prefill_attn: q (bs, nh, n_q, d) and k, v (bs, nh_k, n_kv, d) expected, got {tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}")
+    bs, nh, n_q, d = q.shape
+    nh_k, n_kv = k.shape[1], k.shape[2]
+    if nh % nh_k:
+        raise RuntimeError(f"prefill_attn: nh={nh} is not a multiple of nh_k={nh_k}")
+    fix = lambda t: t if (t.stride(3) == 1 and all(s_ % 8 == 0 for s_ in t.stride()[:3])) else t.contiguous()
+    q, k, v = fix(q), fix(k), fix(v)
+    if out is None:
+        out = torch.empty(bs, nh, n_q, d, dtype=torch.float16, device=q.device)
+    elif out.shape != (bs, nh, n_q, d) or out.dtype != torch.float16 or out.stride(3) != 1:
+        raise RuntimeError("prefill_attn: out must be fp16 (bs, nh, n_q, d) with contiguous rows")
+    desc = L.PrefillDesc()
+    desc.struct_size = ctypes.sizeof(L.PrefillDesc)
+    desc.bs, desc.nh, desc.nh_k, desc.d = bs, nh, nh_k, d
+    desc.n_q, desc.n_kv, desc.q_pos0, desc.causal = n_q, n_kv, q_pos0, int(causal)
+    desc.q_stride_b, desc.q_stride_h, desc.q_stride_n = q.stride(0), q.stride(1), q.stride(2)
+    desc.k_stride_b, desc.k_stride_h, desc.k_stride_n = k.stride(0), k.stride(1), k.stride(2)
+    desc.v_stride_b, desc.v_stride_h, desc.v_stride_n = v.stride(0), v.stride(1), v.stride(2)
+    desc.o_stride_b, desc.o_stride_h, desc.o_stride_n = out.stride(0), out.stride(1), out.stride(2)
+    L.check(L.load().million_prefill_attn(ctypes.byref(desc), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _stream()),
+            "million_prefill_attn")
+    return out
+
+
 def residual_append(k_new: torch.Tensor, v_new: torch.Tensor, k_res: torch.Tensor, v_res: torch.Tensor, r: int,
                     resid_start: int = 0, dev_lengths: Optional[torch.Tensor] = None) -> None:
     """Write the new token's K/V rows into the residual window (replaces pq_utils.py:304-312)."""

@@ -182,12 +182,9 @@ class _CacheBase:
             self._kprep = self._vprep = None
 
     def _prefill_attention(self, q, k, v):
-        """Prefill attention is outside the PQ hot path (reference: torch SDPA, pq_utils.py:249-260)."""
-        from torch.nn.functional import scaled_dot_product_attention as sdpa
-        G = q.size(1) // k.size(1)
-        if G > 1:
-            k, v = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
-        return sdpa(q, k, v, is_causal=True)
+        """Causal attention of the prompt on its own fp16 K/V (reference: repeat_kv + torch SDPA, pq_utils.py:249-260):
+        the MFMA flash kernel of this library (csrc/prefill.hip), the G query heads of a kv head sharing its K/V tiles."""
+        return ops.prefill_attn(q, k, v, causal=True)
 
 
 class DynamicPQCache(_CacheBase):

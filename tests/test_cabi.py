@@ -33,13 +33,14 @@ def test_struct_sizes_match_header(lib):
     """ctypes mirrors must have the C layout: compile a tiny C program against the header."""
     import subprocess, tempfile
     from million_amd import _lib
-    src = '#include "million_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", sizeof(million_encode_desc), sizeof(million_attn_desc));return 0;}\n'
+    src = '#include "million_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(million_encode_desc), sizeof(million_attn_desc), sizeof(million_prefill_desc));return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         (Path(td) / "a.c").write_text(src)
         subprocess.check_call(["gcc", "-std=c11", "-I", str(ROOT / "include"), "-o", f"{td}/a", f"{td}/a.c"])
-        enc, attn = map(int, subprocess.check_output([f"{td}/a"]).split())
+        enc, attn, pre = map(int, subprocess.check_output([f"{td}/a"]).split())
     assert enc == ctypes.sizeof(_lib.EncodeDesc)
     assert attn == ctypes.sizeof(_lib.AttnDesc)
+    assert pre == ctypes.sizeof(_lib.PrefillDesc)
 
 
 def test_argument_validation_without_gpu(lib):

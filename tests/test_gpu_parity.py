@@ -1470,3 +1470,122 @@ def test_fused_append_with_sixteen_heads_per_kv_head(use_dl, env, oracle):
     np.testing.assert_array_equal(kr.cpu().numpy()[:, :, r0:r], k_hist[:, :, r0:r])
     if use_dl:
         assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
+
+
+# ---------------------------------------------------------------- prompt (prefill) attention on fp16 K/V -------------------
+def _sdpa_ref_rows(q, k, v, rows, q_pos0=0, causal=True):
+    """fp64 reference of selected query rows: q (bs, nh, n_q, d), k / v (bs, nh_k, n_kv, d) numpy -> (bs, nh, len(rows), d)."""
+    bs, nh, n_q, d = q.shape
+    nhk, n_kv = k.shape[1], k.shape[2]
+    G = nh // nhk
+    out = np.zeros((bs, nh, len(rows), d))
+    kf, vf = k.astype(np.float64), v.astype(np.float64)
+    for b in range(bs):
+        for h in range(nh):
+            s = q[b, h, rows].astype(np.float64) @ kf[b, h // G].T / np.sqrt(d)      # (rows, n_kv)
+            if causal:
+                j = np.arange(n_kv)[None, :]
+                s = np.where(j <= (q_pos0 + np.asarray(rows))[:, None], s, -np.inf)
+            s = s - s.max(axis=1, keepdims=True)
+            pr = np.exp(s)
+            out[b, h] = (pr / pr.sum(axis=1, keepdims=True)) @ vf[b, h // G]
+    return out
+
+
+@pytest.mark.parametrize("bs,nh,nhk,n_q,n_kv,q_pos0,causal", [
+    (1, 8, 2, 1, 1, 0, True), (1, 8, 2, 33, 33, 0, True), (2, 4, 4, 100, 100, 0, True), (1, 6, 2, 257, 257, 0, True),
+    (1, 8, 1, 300, 300, 0, True), (1, 16, 8, 130, 130, 0, True), (1, 8, 2, 64, 200, 136, True), (1, 8, 2, 70, 333, 0, False),
+    (1, 32, 8, 1000, 1000, 0, True)])
+def test_prefill_attn_small_shapes(bs, nh, nhk, n_q, n_kv, q_pos0, causal, env):
+    """The MFMA prompt-attention kernel (csrc/prefill.hip) against an fp64 reference: ragged lengths (one row, one tile,
+    partial last tile and last query block), every heads-per-workgroup grouping (G = 1, 2, 3 -> 1, 4, 8), batch 2, a
+    prompt chunk behind cached rows (q_pos0 > 0, n_kv > n_q) and the non-causal form."""
+    torch, ops = env
+    rs = np.random.RandomState(900 + n_q + nh)
+    q = rs.standard_normal((bs, nh, n_q, 128)).astype(np.float16)
+    k = rs.standard_normal((bs, nhk, n_kv, 128)).astype(np.float16)
+    v = rs.standard_normal((bs, nhk, n_kv, 128)).astype(np.float16)
+    out = ops.prefill_attn(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(),
+                           causal=causal, q_pos0=q_pos0)
+    torch.cuda.synchronize()
+    gold = _sdpa_ref_rows(q, k, v, list(range(n_q)), q_pos0, causal)
+    _check(out.cpu().numpy(), gold, f"prefill {bs} {nh} {nhk} {n_q} {n_kv}")
+
+
+def test_prefill_attn_strided_inputs_and_peaked_rows(env):
+    """(bs, n, h, d) projections viewed as (bs, h, n, d) (what a model's q/k/v look like before .contiguous()), and a key
+    that dominates late rows (forces the running-maximum rescale of the accumulators)."""
+    torch, ops = env
+    rs = np.random.RandomState(77)
+    bs, nh, nhk, n, d = 1, 8, 2, 400, 128
+    qkv = rs.standard_normal((bs, n, nh + 2 * nhk, d)).astype(np.float16)
+    qkv[0, 300, nh] = 6.0 * qkv[0, 350, 0]          # key 300 of kv head 0 lines up with query 350 of head 0
+    t = torch.from_numpy(qkv).cuda()
+    q, k, v = t[:, :, :nh].transpose(1, 2), t[:, :, nh:nh + nhk].transpose(1, 2), t[:, :, nh + nhk:].transpose(1, 2)
+    out = ops.prefill_attn(q, k, v)
+    torch.cuda.synchronize()
+    gold = _sdpa_ref_rows(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), list(range(n)))
+    _check(out.cpu().numpy(), gold, "prefill strided")
+    with pytest.raises(RuntimeError):
+        ops.prefill_attn(q.float(), k, v)
+    with pytest.raises(RuntimeError):
+        ops.prefill_attn(torch.zeros(1, 8, 4, 64, dtype=torch.float16, device="cuda"),
+                         torch.zeros(1, 2, 4, 64, dtype=torch.float16, device="cuda"),
+                         torch.zeros(1, 2, 4, 64, dtype=torch.float16, device="cuda"))      # d = 64: not built
+
+
+def test_prefill_attn_llama_4k_vs_torch_fp32(env):
+    """(1, 32 q heads, 8 kv heads, 4096 tokens, d 128): every output row against torch's fp32 CPU
+    scaled_dot_product_attention(q, repeat_kv(k), repeat_kv(v), is_causal=True) - the reference's prompt attention
+    (pq_utils.py:249-260) in fp32."""
+    torch, ops = env
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(1, 32, 4096, 128, generator=g).half()
+    k = torch.randn(1, 8, 4096, 128, generator=g).half()
+    v = torch.randn(1, 8, 4096, 128, generator=g).half()
+    out = ops.prefill_attn(q.cuda(), k.cuda(), v.cuda())
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(4, dim=1),
+                                                           v.float().repeat_interleave(4, dim=1), is_causal=True)
+    _check(out.cpu().numpy(), ref.numpy(), "prefill 4k vs torch fp32")
+
+
+def test_prefill_attn_32k_sampled_rows(env):
+    """BASELINE configs[2]'s prompt length: (1, 32, 8, 32768, 128); sampled query rows (first, tile edges, last) of every
+    head against the fp64 reference."""
+    torch, ops = env
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(1, 32, 32768, 128, generator=g, device="cuda").half()
+    k = torch.randn(1, 8, 32768, 128, generator=g, device="cuda").half()
+    v = torch.randn(1, 8, 32768, 128, generator=g, device="cuda").half()
+    out = ops.prefill_attn(q, k, v)
+    torch.cuda.synchronize()
+    rows = [0, 1, 63, 64, 65, 4095, 4096, 20000, 32703, 32704, 32767]
+    gold = _sdpa_ref_rows(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), rows)
+    _check(out[:, :, rows].cpu().numpy(), gold, "prefill 32k sampled rows")
+
+
+def test_paged_cache_prefill_uses_hip_attention(env, oracle):
+    """PagedPQCache.prefill / DynamicPQCache.prefill return the prompt attention of this library's kernel (no torch SDPA,
+    no repeat_kv), also with distort_recent (the dequantised prompt is attended to)."""
+    torch, ops = env
+    from million_amd.pq_cache import DynamicPQCache, PagedPQCache
+    rs = np.random.RandomState(31)
+    bs, nh, nhk, n, d, M = 1, 8, 2, 200, 128, 64
+    q = rs.standard_normal((bs, nh, n, d)).astype(np.float16)
+    k = rs.standard_normal((bs, nhk, n, d)).astype(np.float16)
+    v = rs.standard_normal((bs, nhk, n, d)).astype(np.float16)
+    cents = rs.standard_normal((M, 256, 2)).astype(np.float16)
+    gold = _sdpa_ref_rows(q, k, v, list(range(n)))
+    for cls in (PagedPQCache, DynamicPQCache):
+        cache = cls(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, max_tokens=1024, device="cuda")
+        cache.set_cent(torch.from_numpy(cents).cuda(), torch.from_numpy(cents).cuda())
+        out = cache.prefill(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(), 0)
+        torch.cuda.synchronize()
+        _check(out.cpu().numpy(), gold, cls.__name__)
+    dyn = DynamicPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, max_tokens=1024, device="cuda")
+    dyn.set_cent(torch.from_numpy(cents).cuda(), torch.from_numpy(cents).cuda())
+    out = dyn.prefill(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(), 0, distort_recent=True)
+    kq = oracle.pq_decode(oracle.pq_encode(k, cents), cents).astype(np.float16)
+    vq = oracle.pq_decode(oracle.pq_encode(v, cents), cents).astype(np.float16)
+    _check(out.cpu().numpy(), _sdpa_ref_rows(q, kq, vq, list(range(n))), "distort_recent")
