@@ -220,7 +220,7 @@ void million_set_force_generic(int on);
  * PagedPQCache.prefill; baseline: scripts/modeldb/models/modeling_llama.py:403-443) - GQA without materialising
  * repeat_kv: the nh / nh_k query heads of a kv head share the K/V tiles of one workgroup.
  *   out[b,h,i,:] = softmax_{j <= q_pos0 + i (causal), j < n_kv}( q[b,h,i,:] . k[b,hk,j,:] / sqrt(d) ) v[b,hk,j,:],  hk = h / (nh/nh_k)
- * fp16 in / out, fp32 scores, online softmax and accumulation; d = 128.  causal = 0: every key (j < n_kv).
+ * fp16 in / out, fp32 scores, online softmax and accumulation; d = 128 or 64.  causal = 0: every key (j < n_kv).
  * torch's is_causal=True with q_len == kv_len is q_pos0 = 0; a prompt chunk behind n_past cached fp16 rows is q_pos0 = n_past. */
 typedef struct {
     uint32_t struct_size;         /* = sizeof(million_prefill_desc) */

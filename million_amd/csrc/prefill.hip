@@ -12,10 +12,9 @@
 //     HPW = the largest of {8, 4, 2, 1} dividing G.  Linear block id -> kv head fastest (8 kv heads = 8 XCDs: every
 //     workgroup that reads a kv head's K/V runs on one XCD, next to its L2), heaviest (last) query blocks first.
 //   * K/V tiles of 64 keys go global -> registers -> LDS, issued one tile ahead (registers filled while the current tile
-//     is computed, written to the other LDS buffer afterwards: one barrier per tile); LDS image of a [64][128] fp16 tile:
-//     off(row, 16-byte chunk ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))): conflict-free both for
-//     the row reads (ds_read_b128, K as the A operand) and for the transposed reads (ds_read_b64_tr_b16, V^T as the A
-//     operand) - cdna_hip_programming.md T10 "one image for row reads AND transposed reads", image (b).
+//     is computed, written to the other LDS buffer afterwards: one barrier per tile); ONE LDS image serves the row reads
+//     (ds_read_b128, K as the A operand) and the transposed reads (ds_read_b64_tr_b16, V^T as the A operand), both
+//     conflict-free (pf_off: cdna_hip_programming.md T10 image (b) for d = 128, a searched swizzle for d = 64).
 //   * everything is computed TRANSPOSED so that a query row lives on a lane: S^T = K Q^T (A = K rows from LDS, B = Q^T
 //     from registers, v_mfma_f32_32x32x16_f16): lane (q, h) holds 16 of a 32-key tile's scores of query q; softmax is
 //     in-lane plus ONE half-wave exchange; P^T, converted pairwise to fp16, IS the B operand of O^T += V^T P^T (the
@@ -49,16 +48,29 @@ struct PrefillParams {
 
 constexpr int kPW = 8;            // waves
 constexpr int kKV = 64;           // keys per tile
-constexpr int kTileBytes = kKV * 256;      // one [64][128] fp16 tile
 
+// LDS image of a [64 keys][D] fp16 tile; off(row, ch) = byte offset of 16-byte chunk ch of a row.  D = 128 (256-byte rows):
+// image (b) of cdna_hip_programming.md T10.  D = 64 (128-byte rows, two to a bank row): slot = ((row & 1) << 3 | ch) ^
+// (((rp & 1) << 2) | ((rp >> 2) & 3)) with rp = row >> 1 - found by exhaustive search over the linear maps rp -> 4 bits for
+// the one that leaves BOTH the ds_read_b128 row reads of the 32x32x16 A operand and the ds_read_b64_tr_b16 reads
+// conflict-free (checked lane group by lane group against the bank rules of MI355X_MICROARCH.md, LDS).
+template <int D>
 __device__ __forceinline__ unsigned pf_off(int row, int ch) {
-    return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    if (D == 128) return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    const int rp = row >> 1;
+    return 256u * rp + 16u * ((((row & 1) << 3) | ch) ^ (((rp & 1) << 2) | ((rp >> 2) & 3)));
 }
 typedef __attribute__((address_space(3))) pv4u *lds_v4u_p;
 typedef __attribute__((address_space(3))) pv4s *lds_v4s_p;
 
-// D = 128 only (the Llama head size of every BASELINE config).
+// D = 128 (the Llama head size of every BASELINE config) and D = 64 (the other head size the reference builds, setup.py:12).
+template <int D>
 __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams p) {
+    constexpr int DS = D / 16;                 // k-steps of the score product
+    constexpr int NB = D / 32;                 // 32-row blocks of O^T
+    constexpr int CPR = D / 8;                 // 16-byte chunks per row
+    constexpr int kTileBytes = kKV * 2 * D;    // one [64][D] fp16 tile
+    constexpr int NCH = kKV * CPR / (kPW * 64);      // chunks of a tile per thread (2 / 1)
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];      // [2 buffers][K tile | V tile]
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_smem != 0u) __builtin_trap();      // absolute LDS addressing below
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,12 +94,12 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     const int q_pos = p.q_pos0 + q_row;           // its position among the keys (causal: keys <= q_pos)
 
     // ---- Q^T fragments: B operand, lane (q, h): Q[q][16 s + 8 h .. + 8] ----
-    v8h qf[8];
+    v8h qf[DS];
     {
         const int qr = q_row < p.n_q ? q_row : p.n_q - 1;
         const f16 *qp = p.q + b * p.q_sb + head * p.q_sh + (long long)qr * p.q_sn + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qf[s] = *(const v8h *)(qp + 16 * s);
+        for (int s = 0; s < DS; ++s) qf[s] = *(const v8h *)(qp + 16 * s);
     }
     // ---- key tiles of this workgroup / of this wave ----
     const int wg_q_hi = qb * QB + QB - 1 < p.n_q - 1 ? qb * QB + QB - 1 : p.n_q - 1;      // last query row of the workgroup
@@ -100,11 +112,11 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     // ---- staging: thread -> two 16-byte chunks of the K tile and two of the V tile ----
     const f16 *kbase = p.k + b * p.k_sb + hk * p.k_sh;
     const f16 *vbase = p.v + b * p.v_sb + hk * p.v_sh;
-    pv4u kreg[2], vreg[2];
+    pv4u kreg[NCH], vreg[NCH];
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 512 * i, row = c >> 4, ch = c & 15;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 512 * i, row = c / CPR, ch = c % CPR;
             int kvr = t * kKV + row;
             kvr = kvr < p.n_kv ? kvr : p.n_kv - 1;      // clamped: rows past the end are masked below
             kreg[i] = *(const pv4u *)(kbase + (long long)kvr * p.k_sn + 8 * ch);
@@ -113,17 +125,17 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 512 * i, row = c >> 4, ch = c & 15;
-            const unsigned o = 2u * kTileBytes * buf + pf_off(row, ch);
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 512 * i, row = c / CPR, ch = c % CPR;
+            const unsigned o = 2u * kTileBytes * buf + pf_off<D>(row, ch);
             *(lds_v4u_p)(size_t)o = kreg[i];
             *(lds_v4u_p)(size_t)(o + kTileBytes) = vreg[i];
         }
     };
 
-    v16f O[4];
+    v16f O[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) O[i][j] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;      // m in the scaled exp2 domain
@@ -146,9 +158,9 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
 #pragma unroll
             for (int j = 0; j < 16; ++j) { S0[j] = 0.f; S1[j] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const v8h a0 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off(r32, 2 * s + hh)));
-                const v8h a1 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off(32 + r32, 2 * s + hh)));
+            for (int s = 0; s < DS; ++s) {
+                const v8h a0 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off<D>(r32, 2 * s + hh)));
+                const v8h a1 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off<D>(32 + r32, 2 * s + hh)));
                 S0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[s], S0, 0, 0, 0);
                 S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[s], S1, 0, 0, 0);
             }
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
             if (__any(m_new > m_run && m_run > -INFINITY)) {      // some row's maximum moved: rescale (lane-local: a row is a lane)
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NB; ++i)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) O[i][j] *= alpha;
                 l_run *= alpha;
@@ -209,10 +221,10 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
                     const int kvr0 = 32 * jt + 16 * ks + 4 * hh;
                     const int qd = (lane >> 2) & 3, pp = lane & 3, g16 = (lane >> 4) & 1;      // lane 4 qd + pp of its 16-lane group
 #pragma unroll
-                    for (int blk = 0; blk < 4; ++blk) {
+                    for (int blk = 0; blk < NB; ++blk) {
                         const int chn = 4 * blk + 2 * g16 + (pp >> 1);
-                        const pv4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off(kvr0 + qd, chn) + 8 * (pp & 1)));
-                        const pv4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off(kvr0 + 8 + qd, chn) + 8 * (pp & 1)));
+                        const pv4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off<D>(kvr0 + qd, chn) + 8 * (pp & 1)));
+                        const pv4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off<D>(kvr0 + 8 + qd, chn) + 8 * (pp & 1)));
                         typedef short v8s __attribute__((ext_vector_type(8)));
                         const v8s av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         O[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, av), pb, O[blk], 0, 0, 0);
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         f16 *op = p.out + b * p.o_sb + head * p.o_sh + (long long)q_row * p.o_sn + 4 * hh;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 typedef f16 h4 __attribute__((ext_vector_type(4)));
@@ -255,9 +267,13 @@ int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
     const long long blocks = (long long)p.bs * p.nh_k * (p.G / hpw) * p.n_qb;
     if (blocks <= 0) return MILLION_OK;
     if (blocks > 0x7fffffffLL) { set_error("prefill: %lld workgroups", blocks); return MILLION_ERR_SHAPE; }
-    const int lds = 4 * kTileBytes;      // two buffers of (K tile, V tile)
-    if (device_once(3)) (void)hipFuncSetAttribute((const void *)prefill_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(prefill_attn_kernel, dim3((unsigned)blocks), dim3(kPW * 64), lds, s, p);
+    const int lds = 4 * kKV * 2 * p.d;      // two buffers of (K tile, V tile)
+    if (device_once(3)) {
+        (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 256);
+        (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 128);
+    }
+    if (p.d == 128) hipLaunchKernelGGL(prefill_attn_kernel<128>, dim3((unsigned)blocks), dim3(kPW * 64), lds, s, p);
+    else hipLaunchKernelGGL(prefill_attn_kernel<64>, dim3((unsigned)blocks), dim3(kPW * 64), lds, s, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("prefill launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
     return MILLION_OK;
@@ -276,7 +292,7 @@ extern "C" int million_prefill_attn(const million_prefill_desc *desc, const void
     p.bs = desc->bs; p.nh = desc->nh; p.nh_k = desc->nh_k; p.d = desc->d;
     p.n_q = desc->n_q; p.n_kv = desc->n_kv; p.q_pos0 = desc->q_pos0; p.causal = desc->causal != 0;
     if (p.bs <= 0 || p.nh <= 0 || p.nh_k <= 0 || p.nh % p.nh_k) { set_error("prefill: bs=%d nh=%d nh_k=%d", p.bs, p.nh, p.nh_k); return MILLION_ERR_SHAPE; }
-    if (p.d != 128) { set_error("prefill: d=%d (128 only)", p.d); return MILLION_ERR_SHAPE; }
+    if (p.d != 128 && p.d != 64) { set_error("prefill: d=%d (64 or 128)", p.d); return MILLION_ERR_SHAPE; }
     if (p.n_q < 0 || p.n_kv < 0 || p.q_pos0 < 0) { set_error("prefill: n_q=%d n_kv=%d q_pos0=%d", p.n_q, p.n_kv, p.q_pos0); return MILLION_ERR_ARG; }
     if (p.n_q == 0) return MILLION_OK;
     if (p.n_kv == 0) { set_error("prefill: no keys (n_kv = 0) for %d query rows", p.n_q); return MILLION_ERR_ARG; }

@@ -1529,9 +1529,25 @@ def test_prefill_attn_strided_inputs_and_peaked_rows(env):
     with pytest.raises(RuntimeError):
         ops.prefill_attn(q.float(), k, v)
     with pytest.raises(RuntimeError):
-        ops.prefill_attn(torch.zeros(1, 8, 4, 64, dtype=torch.float16, device="cuda"),
-                         torch.zeros(1, 2, 4, 64, dtype=torch.float16, device="cuda"),
-                         torch.zeros(1, 2, 4, 64, dtype=torch.float16, device="cuda"))      # d = 64: not built
+        ops.prefill_attn(torch.zeros(1, 8, 4, 32, dtype=torch.float16, device="cuda"),
+                         torch.zeros(1, 2, 4, 32, dtype=torch.float16, device="cuda"),
+                         torch.zeros(1, 2, 4, 32, dtype=torch.float16, device="cuda"))      # d = 32: not a head size of the reference
+
+
+@pytest.mark.parametrize("bs,nh,nhk,n_q,n_kv,q_pos0,causal", [(1, 8, 2, 1, 1, 0, True), (2, 8, 8, 257, 257, 0, True),
+                                                                (1, 6, 2, 333, 333, 0, True), (1, 16, 2, 64, 500, 436, True),
+                                                                (1, 8, 4, 130, 700, 0, False), (1, 32, 8, 2048, 2048, 0, True)])
+def test_prefill_attn_d64(bs, nh, nhk, n_q, n_kv, q_pos0, causal, env):
+    """Head size 64 (the reference's other build, setup.py:12): 128-byte LDS rows with their own swizzle."""
+    torch, ops = env
+    rs = np.random.RandomState(1900 + n_q + nh)
+    q = rs.standard_normal((bs, nh, n_q, 64)).astype(np.float16)
+    k = rs.standard_normal((bs, nhk, n_kv, 64)).astype(np.float16)
+    v = rs.standard_normal((bs, nhk, n_kv, 64)).astype(np.float16)
+    out = ops.prefill_attn(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(),
+                           causal=causal, q_pos0=q_pos0)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), _sdpa_ref_rows(q, k, v, list(range(n_q)), q_pos0, causal), f"prefill d64 {nh} {nhk} {n_q} {n_kv}")
 
 
 def test_prefill_attn_llama_4k_vs_torch_fp32(env):
