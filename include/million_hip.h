@@ -106,10 +106,12 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
  * dst_layout = MILLION_CODES_KPAGES into k_pool; the V side is written as MILLION_CODES_VPAGES into v_pool through the
  * same page ids.  dev_lengths (must equal desc->dev_lengths; may be NULL): the destination token and the ring start are
  * read on the device and, once every workgroup has read them, advanced there (n_tokens += n, r -= n, resid_start =
- * (resid_start + n) % resid_cap; the 4th word of each row is the workgroups' ticket and is left at 0).  uint8 codes. */
+ * (resid_start + n) % resid_cap; the 4th word of each row is the workgroups' ticket and is left at 0).  uint8 codes.
+ * min_r (device lengths only; 0 = every batch item): batch items whose window holds fewer than min_r rows are left alone -
+ * requests of different lengths share the launch and only those whose window is full flush (pass resid_cap). */
 int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const void *v_rows,
                      const void *k_cents, const void *v_cents, void *k_pool, void *v_pool,
-                     const int32_t *page_ids, int32_t *dev_lengths, int resid_cap, million_stream_t stream);
+                     const int32_t *page_ids, int32_t *dev_lengths, int resid_cap, int min_r, million_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PQ decode (reconstruction).

@@ -224,6 +224,7 @@ struct FlushParams {
     EncParams k, v;
     int *dev_lengths_w;      // writable alias of k.dev_lengths (null: host lengths, nothing to advance)
     int n_flush, rcap;
+    int min_r;               // device lengths only: batch items whose window holds fewer rows are skipped (0: flush every item)
     int hp;                  // kv heads per workgroup (1..16)
     int hgroups;             // ceil(nh_k / hp)
 };
@@ -253,7 +254,12 @@ __global__ __launch_bounds__(kFlushWaves * 64) void pq_flush_kernel(FlushParams 
     if ((int)threadIdx.x < C * DM) cv = cm[threadIdx.x];
     // (2) lengths -> window row of this lane and the page id of the destination token, one round trip
     int tok0 = p.tok0, xrow_start = p.xrow_start;
-    if (p.dev_lengths) { tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2]; }
+    if (p.dev_lengths) {
+        tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2];
+        // ragged batches: only the requests whose window is full are flushed (every workgroup of item b decides alike,
+        // before any barrier and before the ticket)
+        if (f.min_r > 0 && p.dev_lengths[b * 4 + 1] < f.min_r) return;
+    }
     // device-resident values are not trusted (cf. clamp_lengths): a start outside the ring becomes 0, a destination
     // outside the page table drops the store
     if (p.xrow_mod > 0 && (unsigned)xrow_start >= (unsigned)p.xrow_mod) xrow_start = 0;
@@ -331,11 +337,11 @@ __global__ __launch_bounds__(kFlushWaves * 64) void pq_flush_kernel(FlushParams 
     }
 }
 
-int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, hipStream_t s) {
+int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, int min_r, hipStream_t s) {
     if (k.n <= 0 || k.bs * k.nh_k <= 0) return MILLION_OK;
     if (k.C > 256) { set_error("flush: uint8 codes only (C=%d)", k.C); return MILLION_ERR_SHAPE; }
     FlushParams f;
-    f.k = k; f.v = v; f.dev_lengths_w = dev_lengths_w; f.n_flush = k.n; f.rcap = rcap;
+    f.k = k; f.v = v; f.dev_lengths_w = dev_lengths_w; f.n_flush = k.n; f.rcap = rcap; f.min_r = dev_lengths_w ? min_r : 0;
     // kv heads per workgroup: as many as fit its 16 waves, halved while the grid would leave CUs idle
     const int tblocks = (k.n + 63) / 64;
     int hp = k.nh_k < kFlushWaves ? k.nh_k : kFlushWaves;

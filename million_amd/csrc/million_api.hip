@@ -1,6 +1,7 @@
 // million_api.hip — C-ABI entry points of libmillion_hip.so (see include/million_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -279,7 +280,7 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
 
 int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const void *v_rows, const void *k_cents,
                      const void *v_cents, void *k_pool, void *v_pool, const int32_t *page_ids, int32_t *dev_lengths,
-                     int resid_cap, million_stream_t stream) {
+                     int resid_cap, int min_r, million_stream_t stream) {
     EncParams k, v;
     int rc = fill_enc_params("flush", desc, k_rows, k_cents, k_pool, page_ids, k);
     if (rc != MILLION_OK) return rc;
@@ -290,7 +291,8 @@ int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const 
     if (resid_cap <= 0) { set_error("flush: resid_cap=%d", resid_cap); return MILLION_ERR_ARG; }
     if ((const int32_t *)dev_lengths != desc->dev_lengths) { set_error("flush: dev_lengths must equal desc->dev_lengths (or both null)"); return MILLION_ERR_ARG; }
     v.layout = MILLION_CODES_VPAGES;
-    return launch_flush(k, v, dev_lengths, resid_cap, (hipStream_t)stream);
+    if (min_r < 0 || min_r > resid_cap) { set_error("flush: min_r=%d outside [0, resid_cap]", min_r); return MILLION_ERR_ARG; }
+    return launch_flush(k, v, dev_lengths, resid_cap, min_r, (hipStream_t)stream);
 }
 
 int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n_rows, int d, int M, int C,
@@ -352,6 +354,20 @@ static int launch_group(const AttnParams &p, hipStream_t stream) {
             if (rc_fast != kAttnNotHandled) return rc_fast;
         }
         if (attn_tile_supported(p)) return launch_attn_tile(p, stream);
+    }
+    if (!g_force_generic) {
+        // not a silent cliff: the scalar kernel is ~60x slower than the MFMA kernels.  Said once per process
+        // on stderr (MILLION_QUIET=1 silences it); million_attn_kernel_kind() answers the same question without launching.
+        static std::once_flag once;
+        std::call_once(once, [&] {
+            const char *q = getenv("MILLION_QUIET");
+            if (!q || !*q || *q == '0')
+                fprintf(stderr, "libmillion_hip: decode attention fell back to the scalar kernel (d=%d M=%d C=%d, k %s / v %s%s): "
+                                "~60x slower than the MFMA kernels; they take d=128 with M in {64,32} or d in {64,128} with the "
+                                "reference's other (M, C) and V in transposed pages (row-major K and V are transposed for you).\n",
+                        p.d, p.M, p.C, p.k_paged ? "paged" : "row-major", p.v_paged ? "paged" : "row-major",
+                        p.T == 0 ? ", no quantised tokens" : "");
+        });
     }
     AttnParams g = p;
     choose_splits(g, 256);

@@ -304,7 +304,8 @@ class GraphedPQDecoder:
         self._eager_step()                     # allocates workspaces, warms hipBLASLt heuristics
         torch.cuda.synchronize()
         self.graphs = {}
-        for name, r_cap in (("plain", st[1][0] if st[1][0] < cap else 0), ("flush", cap)):
+        r_now = int(st[1][0][0])
+        for name, r_cap in (("plain", r_now if r_now < cap else 0), ("flush", cap)):
             cache.set_host_state((st[0], [r_cap] * L, st[2], st[3]))
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):

@@ -147,10 +147,11 @@ def pq_encode(X: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
 
 def pq_flush(k_rows: torch.Tensor, v_rows: torch.Tensor, k_cents: torch.Tensor, v_cents: torch.Tensor,
              k_pool: torch.Tensor, v_pool: torch.Tensor, page_ids: torch.Tensor, *, n: int, page_size: int,
-             token_start: int = 0, x_row_start: int = 0, dev_lengths: Optional[torch.Tensor] = None) -> None:
+             token_start: int = 0, x_row_start: int = 0, dev_lengths: Optional[torch.Tensor] = None, min_r: int = 0) -> None:
     """One launch per window flush (reference PagedPQCache.flush_to_pages, paged_pq_utils.py:130-210): encode the oldest n
     rows of the K and V windows (rings of k_rows.shape[2] rows) into a K page and a transposed V page; with dev_lengths
-    the destination token and the ring start are read on the device and advanced there."""
+    the destination token and the ring start are read on the device and advanced there; min_r > 0 then skips the batch
+    items whose window holds fewer rows (ragged batches: only the full windows flush)."""
     _need_cuda(k_rows, v_rows, k_cents, v_cents, k_pool, v_pool, page_ids, dev_lengths)
     if k_rows.shape != v_rows.shape or k_rows.stride() != v_rows.stride() or k_rows.dtype != torch.float16 or v_rows.dtype != torch.float16:
         raise RuntimeError("pq_flush: K and V windows must be fp16 with the same shape and strides")
@@ -173,7 +174,7 @@ def pq_flush(k_rows: torch.Tensor, v_rows: torch.Tensor, k_cents: torch.Tensor, 
     desc.dev_lengths = _ptr(dev_lengths)
     L.check(L.load().million_pq_flush(ctypes.byref(desc), k_rows.data_ptr(), v_rows.data_ptr(), k_cents.data_ptr(),
                                       v_cents.data_ptr(), k_pool.data_ptr(), v_pool.data_ptr(), page_ids.data_ptr(),
-                                      _ptr(dev_lengths), cap, _stream()), "million_pq_flush")
+                                      _ptr(dev_lengths), cap, min_r if dev_lengths is not None else 0, _stream()), "million_pq_flush")
 
 
 def transpose_v_codes(v_codes: torch.Tensor, n_tokens: Optional[int] = None) -> torch.Tensor:

@@ -308,6 +308,29 @@ class DynamicPQCache(_CacheBase):
         return sum(c.numel() * c.element_size() for c in self.key_residual_cache + self.value_residual_cache)
 
 
+class _PerLayer:
+    """`cache._T[l]`-style access to a (layers, requests) host array: reading gives request 0's value (all requests move in
+    lockstep unless slots are recycled, see PagedPQCache.release), writing sets every request of the layer."""
+
+    def __init__(self, arr):
+        self._a = arr
+
+    def __getitem__(self, l):
+        return int(self._a[l, 0])
+
+    def __setitem__(self, l, v):
+        self._a[l, :] = v
+
+    def __len__(self):
+        return self._a.shape[0]
+
+    def __iter__(self):
+        return (int(x) for x in self._a[:, 0])
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 class PagedPQCache(_CacheBase):
     """Paged code store: K pages (page_size, M) row-major, V pages (M, page_size) transposed, a residual
     ring of `extended_residual_size` rows; when r reaches it the OLDEST page_size rows are flushed
@@ -315,7 +338,12 @@ class PagedPQCache(_CacheBase):
 
     One global pool per side serves all layers; page ids are handed out by a PageManager.  With
     `preallocate=True` (default) the page table of every (layer, b, hk) is filled for `max_tokens` at
-    init, so decode steps touch no host state and are hipGraph-capturable."""
+    init, so decode steps touch no host state and are hipGraph-capturable.
+
+    Lengths are kept per (layer, request) - on the host (numpy, (layers, bs)) and on the device (`lengths[l]`, int32
+    (bs, 4)) - so that a batch slot can finish and be recycled while the others keep decoding: `release(b)` returns the
+    slot's pages and zeroes its lengths, `prefill_request(b, ...)` encodes a new prompt into it.  Requests of different
+    lengths share every launch through the device-resident lengths (`use_dev_lengths=True`)."""
 
     def __init__(self, *, bs, nh, num_key_value_heads, M, layer_num, dtype=torch.uint8, nbits=8, d=128,
                  scalar_t=torch.float16, page_size=64, extended_residual_size=128, max_pages_per_layer=None,
@@ -340,6 +368,7 @@ class PagedPQCache(_CacheBase):
         self.init_cache()
 
     def init_cache(self):
+        import numpy as np
         nk, cap = self.num_key_value_heads, self.extended_residual_size
         total = self.layer_num * self.bs * nk * self.n_pages_cap
         z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=self.device)
@@ -347,98 +376,207 @@ class PagedPQCache(_CacheBase):
         self.value_page_pool = z(total, self.M, self.page_size, dt=torch.uint8)
         self.page_manager = PageManager(self.page_size, initial_pages=total, max_pages=total, M=self.M)
         self.page_ids = [z(self.bs, nk, self.n_pages_cap, dt=torch.int32) for _ in range(self.layer_num)]
-        self._pages_assigned = [0] * self.layer_num
         self.key_residual_cache = [z(self.bs, nk, cap, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
         self.value_residual_cache = [z(self.bs, nk, cap, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
         self.lengths = [z(self.bs, 4, dt=torch.int32) for _ in range(self.layer_num)]     # device mirror
-        self.seen_tokens = [0] * self.layer_num
-        self.residualed_tokens = [0] * self.layer_num
-        self._T = [0] * self.layer_num
-        self._rstart = [0] * self.layer_num
+        # host mirrors, (layers, requests)
+        zi = lambda: np.zeros((self.layer_num, self.bs), dtype=np.int64)
+        self._seen_a, self._r_a, self._T_a, self._rs_a, self._pages_a = zi(), zi(), zi(), zi(), zi()
+        self._host_pids = [[[[] for _ in range(nk)] for _ in range(self.bs)] for _ in range(self.layer_num)]
         self._ws = None
         if self.preallocate:
             for l in range(self.layer_num):
-                self._assign_pages(l, self.n_pages_cap)
+                for b in range(self.bs):
+                    self._assign_pages(l, self.n_pages_cap, b)
 
-    def _assign_pages(self, layer_idx, upto_pages):
-        have = self._pages_assigned[layer_idx]
-        if upto_pages <= have:
-            return
-        if upto_pages > self.n_pages_cap:
-            raise RuntimeError(f"PagedPQCache: {upto_pages} pages exceed capacity {self.n_pages_cap} (max_tokens)")
-        n_new = upto_pages - have
-        ids = self.page_manager.allocate_pages(n_new * self.bs * self.num_key_value_heads)
-        t = torch.tensor(ids, dtype=torch.int32).reshape(self.bs, self.num_key_value_heads, n_new)
-        self.page_ids[layer_idx][:, :, have:upto_pages] = t.to(self.device)
-        self._pages_assigned[layer_idx] = upto_pages
+    # per-layer views with the reference's names (request 0's value; assignment sets every request)
+    seen_tokens = property(lambda self: _PerLayer(self._seen_a), lambda self, v: self._set_rows(self._seen_a, v))
+    residualed_tokens = property(lambda self: _PerLayer(self._r_a), lambda self, v: self._set_rows(self._r_a, v))
+    _T = property(lambda self: _PerLayer(self._T_a), lambda self, v: self._set_rows(self._T_a, v))
+    _rstart = property(lambda self: _PerLayer(self._rs_a), lambda self, v: self._set_rows(self._rs_a, v))
+    _pages_assigned = property(lambda self: _PerLayer(self._pages_a))
+
+    @staticmethod
+    def _set_rows(arr, v):
+        import numpy as np
+        v = np.asarray([list(x) if hasattr(x, "__len__") else x for x in v] if not isinstance(v, np.ndarray) else v)
+        arr[...] = v if v.ndim == 2 else v[:, None]
+
+    def _lockstep(self, layer_idx) -> bool:
+        a = (self._T_a[layer_idx], self._r_a[layer_idx], self._rs_a[layer_idx])
+        return all((x == x[0]).all() for x in a)
+
+    def _assign_pages(self, layer_idx, upto_pages, b=None):
+        """Page ids for pages [have, upto_pages) of every kv head of request b (None: every request)."""
+        for bb in (range(self.bs) if b is None else (b,)):
+            have = int(self._pages_a[layer_idx, bb])
+            if upto_pages <= have:
+                continue
+            if upto_pages > self.n_pages_cap:
+                raise RuntimeError(f"PagedPQCache: {upto_pages} pages exceed capacity {self.n_pages_cap} (max_tokens)")
+            n_new = upto_pages - have
+            nk = self.num_key_value_heads
+            ids = self.page_manager.allocate_pages(n_new * nk)
+            for h in range(nk):
+                self._host_pids[layer_idx][bb][h].extend(ids[h * n_new:(h + 1) * n_new])
+            t = torch.tensor(ids, dtype=torch.int32).reshape(nk, n_new)
+            self.page_ids[layer_idx][bb, :, have:upto_pages] = t.to(self.device)
+            self._pages_a[layer_idx, bb] = upto_pages
 
     def _sync_lengths(self, layer_idx):
-        self.lengths[layer_idx][:, 0] = self._T[layer_idx]
-        self.lengths[layer_idx][:, 1] = self.residualed_tokens[layer_idx]
-        self.lengths[layer_idx][:, 2] = self._rstart[layer_idx]
+        import numpy as np
+        rows = np.stack([self._T_a[layer_idx], self._r_a[layer_idx], self._rs_a[layer_idx], np.zeros(self.bs, dtype=np.int64)], axis=1)
+        self.lengths[layer_idx].copy_(torch.from_numpy(rows.astype(np.int32)))
 
-    def _encode_to_pages(self, K, V, layer_idx, n, *, from_ring=False, use_dev_lengths=False):
-        T = self._T[layer_idx]
+    def _encode_to_pages(self, K, V, layer_idx, n, *, b=None):
+        """Encode n rows of K, V (bs or 1, nh_k, n, d) behind the T quantised tokens of every request (b = None: requests
+        in lockstep) or of request b."""
+        sel = slice(None) if b is None else slice(b, b + 1)
+        T = int(self._T_a[layer_idx, 0 if b is None else b])
         if not self.preallocate:
-            self._assign_pages(layer_idx, (T + n + self.page_size - 1) // self.page_size)
+            self._assign_pages(layer_idx, (T + n + self.page_size - 1) // self.page_size, b)
         elif T + n > self.max_tokens:
             raise RuntimeError(f"PagedPQCache: {T + n} tokens exceed max_tokens={self.max_tokens}")
-        kw = dict(token_start=T, n=n, page_ids=self.page_ids[layer_idx], page_size=self.page_size)
-        if from_ring:
-            kw.update(x_row_start=self._rstart[layer_idx], x_row_mod=self.extended_residual_size)
-        if use_dev_lengths:
-            kw.update(dev_lengths=self.lengths[layer_idx])
+        kw = dict(token_start=T, n=n, page_ids=self.page_ids[layer_idx][sel], page_size=self.page_size)
         ops.pq_encode_into(K, self.key_cent, self.key_page_pool, layout=L.MILLION_CODES_KPAGES, prepared=self._kprep, **kw)
         ops.pq_encode_into(V, self.value_cent, self.value_page_pool, layout=L.MILLION_CODES_VPAGES, prepared=self._vprep, **kw)
 
     def prefill(self, query_states, key_states, value_states, layer_idx, distort_recent=False):
         """Bulk encode of the prompt straight into pages (reference paged_pq_utils.py:216-320: encode,
         torch.cat, per-page permute+contiguous); the residual window stays empty."""
+        if not self._lockstep(layer_idx):
+            raise RuntimeError("PagedPQCache.prefill: requests are at different lengths; use prefill_request(b, ...)")
         n = key_states.size(2)
         self._encode_to_pages(key_states, value_states, layer_idx, n)
-        self._T[layer_idx] += n
-        self.seen_tokens[layer_idx] += n
+        self._T_a[layer_idx] += n
+        self._seen_a[layer_idx] += n
         self._sync_lengths(layer_idx)
         return self._prefill_attention(query_states, key_states, value_states)
+
+    def prefill_request(self, b, query_states, key_states, value_states, layer_idx):
+        """The prompt of ONE request (tensors of batch 1) into batch slot b, the other slots untouched - a recycled slot
+        (release) starts its next request while the rest of the batch keeps decoding."""
+        if key_states.size(0) != 1 or self._T_a[layer_idx, b] or self._r_a[layer_idx, b]:
+            raise RuntimeError("prefill_request: tensors of batch 1 into an empty slot (release it first)")
+        n = key_states.size(2)
+        self._encode_to_pages(key_states, value_states, layer_idx, n, b=b)
+        self._T_a[layer_idx, b] += n
+        self._seen_a[layer_idx, b] += n
+        self._sync_lengths(layer_idx)
+        return self._prefill_attention(query_states, key_states, value_states)
+
+    def release(self, b):
+        """Request b has finished: its pages go back to the PageManager (on-demand paging; a preallocated table keeps its
+        fixed ids for the slot's next request), its host and device lengths return to zero.  The other slots, and any
+        captured graph (lengths are read on the device), are not touched."""
+        for l in range(self.layer_num):
+            if not self.preallocate:
+                for h in range(self.num_key_value_heads):
+                    for pid in self._host_pids[l][b][h]:
+                        self.page_manager.free_page(pid)
+                    self._host_pids[l][b][h] = []
+                self._pages_a[l, b] = 0
+            self._T_a[l, b] = self._r_a[l, b] = self._rs_a[l, b] = self._seen_a[l, b] = 0
+            self.lengths[l][b].zero_()
+
+    reset_request = release
+
+    def cleanup(self):
+        """Reference PagedPQCache.cleanup (paged_pq_utils.py:1082-1118): drop every request's codes and window; the pools
+        and (preallocated) page tables stay."""
+        for b in range(self.bs):
+            self.release(b)
+        for l in range(self.layer_num):
+            self.key_residual_cache[l].zero_()
+            self.value_residual_cache[l].zero_()
+
+    def _codes_rowmajor(self, layer_idx, T):
+        """(bs, nh_k, T, M) row-major K and V codes gathered from the pages (dequantise-then-attend path only)."""
+        npg = (T + self.page_size - 1) // self.page_size
+        ids = self.page_ids[layer_idx][:, :, :npg].long()
+        kc = self.key_page_pool[ids].reshape(self.bs, self.num_key_value_heads, npg * self.page_size, self.M)[:, :, :T]
+        vc = self.value_page_pool[ids].permute(0, 1, 2, 4, 3).reshape(self.bs, self.num_key_value_heads, npg * self.page_size, self.M)[:, :, :T]
+        return kc.contiguous(), vc.contiguous()
+
+    def update(self, key_states, value_states, layer_idx, distort_recent=False):
+        """The reference's non-kernel path on the paged store (paged_pq_utils.py:322-339 -> pq_utils.py:166-220): encode and
+        store the new K/V rows into pages, return the full-length fp16 K/V for a dense attention - the dequantised past
+        followed by the new rows as they are (or dequantised too with distort_recent).  No residual window on this path."""
+        if not self._lockstep(layer_idx) or self._r_a[layer_idx, 0]:
+            raise RuntimeError("PagedPQCache.update: lockstep requests and an empty residual window expected")
+        n = key_states.size(2)
+        T0 = int(self._T_a[layer_idx, 0])
+        self._encode_to_pages(key_states, value_states, layer_idx, n)
+        self._T_a[layer_idx] += n
+        self._seen_a[layer_idx] += n
+        self._sync_lengths(layer_idx)
+        upto = T0 + n if distort_recent else T0
+        if upto:
+            kc, vc = self._codes_rowmajor(layer_idx, upto)
+            past_k, past_v = ops.pq_decode(kc, self.key_cent), ops.pq_decode(vc, self.value_cent)
+        else:
+            past_k = past_v = None
+        if distort_recent:
+            return past_k, past_v
+        if past_k is None:
+            return key_states, value_states
+        return torch.cat([past_k, key_states.to(past_k.dtype)], dim=2), torch.cat([past_v, value_states.to(past_v.dtype)], dim=2)
 
     def flush_to_pages(self, layer_idx: int, use_dev_lengths=False):
         """Encode the oldest page_size residual rows into a new K page and V page and move the window on
         (paged_pq_utils.py:130-210) - ONE launch (million_pq_flush): K encode, V encode and, with device-resident
-        lengths, their advance."""
-        if self.residualed_tokens[layer_idx] < self.page_size:
+        lengths, their advance.  Requests at different lengths (recycled slots): only those whose window is full flush -
+        the launch reads every request's lengths on the device and skips the others (min_r)."""
+        cap, ps = self.extended_residual_size, self.page_size
+        full = self._r_a[layer_idx] >= cap
+        lock = self._lockstep(layer_idx)
+        if lock and self._r_a[layer_idx, 0] < ps:
             return
-        T = self._T[layer_idx]
-        if not self.preallocate:
-            self._assign_pages(layer_idx, (T + self.page_size + self.page_size - 1) // self.page_size)
-        elif T + self.page_size > self.max_tokens:
-            raise RuntimeError(f"PagedPQCache: {T + self.page_size} tokens exceed max_tokens={self.max_tokens}")
+        if not lock and not full.any():
+            return
+        if not lock and not use_dev_lengths:
+            raise RuntimeError("PagedPQCache: requests at different lengths need use_dev_lengths=True")
+        who = range(self.bs) if lock else [b for b in range(self.bs) if full[b]]
+        for b in who:
+            T = int(self._T_a[layer_idx, b])
+            if not self.preallocate:
+                self._assign_pages(layer_idx, (T + ps + ps - 1) // ps, b)
+            elif T + ps > self.max_tokens:
+                raise RuntimeError(f"PagedPQCache: {T + ps} tokens exceed max_tokens={self.max_tokens}")
         ops.pq_flush(self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], self.key_cent,
                      self.value_cent, self.key_page_pool, self.value_page_pool, self.page_ids[layer_idx],
-                     n=self.page_size, page_size=self.page_size, token_start=T, x_row_start=self._rstart[layer_idx],
-                     dev_lengths=self.lengths[layer_idx] if use_dev_lengths else None)
-        self._T[layer_idx] += self.page_size
-        self.residualed_tokens[layer_idx] -= self.page_size
-        self._rstart[layer_idx] = (self._rstart[layer_idx] + self.page_size) % self.extended_residual_size
+                     n=ps, page_size=ps, token_start=int(self._T_a[layer_idx, 0]), x_row_start=int(self._rs_a[layer_idx, 0]),
+                     dev_lengths=self.lengths[layer_idx] if use_dev_lengths else None,
+                     min_r=cap if use_dev_lengths else 0)      # device lengths: only full windows flush (a captured step serves ragged batches too)
+        for b in who:
+            self._T_a[layer_idx, b] += ps
+            self._r_a[layer_idx, b] -= ps
+            self._rs_a[layer_idx, b] = (self._rs_a[layer_idx, b] + ps) % cap
 
     def decoding_with_pages(self, query_states, key_states, value_states, layer_idx, out=None, use_dev_lengths=False):
         """One decode step of one layer (paged_pq_utils.py:341-386): flush if the window is full, append the
         new token's K/V row, fused attention over pages + window.  With use_dev_lengths=True every length
-        is read on the device (the host mirror is still advanced), which makes the call graph-capturable."""
-        if self.residualed_tokens[layer_idx] >= self.extended_residual_size:           # :359-361
+        is read on the device (the host mirror is still advanced), which makes the call graph-capturable and lets
+        requests of different lengths share the launch."""
+        cap = self.extended_residual_size
+        if (self._r_a[layer_idx] >= cap).any():                                          # :359-361
             self.flush_to_pages(layer_idx, use_dev_lengths=use_dev_lengths)
-        r, rs = self.residualed_tokens[layer_idx], self._rstart[layer_idx]
+        lock = self._lockstep(layer_idx)
+        if not lock and not use_dev_lengths:
+            raise RuntimeError("PagedPQCache: requests at different lengths need use_dev_lengths=True")
+        r, rs = int(self._r_a[layer_idx, 0]), int(self._rs_a[layer_idx, 0])
         dl = self.lengths[layer_idx] if use_dev_lengths else None
         if self._ws is None:      # one workspace per cache (calls of one cache are stream-ordered)
             desc = ops.make_attn_desc(query_states, self.key_residual_cache[layer_idx], nh_k=self.num_key_value_heads,
                                       M=self.M, C=self.C, n_tokens=0, r=0)
             self._ws = torch.zeros(L.load().million_attn_workspace_bytes(desc), dtype=torch.uint8, device=self.device)
-        self.residualed_tokens[layer_idx] = r + 1
-        self.seen_tokens[layer_idx] += 1
+        self._r_a[layer_idx] += 1
+        self._seen_a[layer_idx] += 1
         # append (:377-380) + attention (:386) in ONE launch: the new row is attended to and parked in the window
         return ops.pq_decode_attn(query_states, self.key_page_pool, self.value_page_pool, self._kprep, self._vprep,
                                   self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], r,
                                   k_new=key_states, v_new=value_states,
-                                  M=self.M, C=self.C, n_tokens=self.max_tokens if use_dev_lengths else self._T[layer_idx],
+                                  M=self.M, C=self.C, n_tokens=self.max_tokens if use_dev_lengths else int(self._T_a[layer_idx, 0]),
                                   resid_start=rs, k_page_ids=self.page_ids[layer_idx],
                                   v_page_ids=self.page_ids[layer_idx], page_size=self.page_size, out=out,
                                   dev_lengths=dl, workspace=self._ws)
@@ -451,29 +589,32 @@ class PagedPQCache(_CacheBase):
     # executes; under replay the kernels run but no Python does.  The harness therefore restores the
     # mirror after capture and calls note_replayed_step() after every replay.
     def host_state(self):
-        return (list(self.seen_tokens), list(self.residualed_tokens), list(self._T), list(self._rstart))
+        """(seen, r, T, resid_start), each (layers, requests) - what set_host_state takes back (it also takes one value per
+        layer for all requests)."""
+        return (self._seen_a.copy(), self._r_a.copy(), self._T_a.copy(), self._rs_a.copy())
 
     def set_host_state(self, st):
-        self.seen_tokens, self.residualed_tokens, self._T, self._rstart = (list(x) for x in st)
+        for arr, v in zip((self._seen_a, self._r_a, self._T_a, self._rs_a), st):
+            self._set_rows(arr, v)
 
     def next_step_flushes(self, layer_idx: int = 0) -> bool:
-        return self.residualed_tokens[layer_idx] >= self.extended_residual_size
+        return bool((self._r_a[layer_idx] >= self.extended_residual_size).any())
 
     def note_replayed_step(self):
-        for l in range(self.layer_num):
-            if self.residualed_tokens[l] >= self.extended_residual_size:
-                self._T[l] += self.page_size
-                self.residualed_tokens[l] -= self.page_size
-                self._rstart[l] = (self._rstart[l] + self.page_size) % self.extended_residual_size
-            self.residualed_tokens[l] += 1
-            self.seen_tokens[l] += 1
+        cap, ps = self.extended_residual_size, self.page_size
+        full = self._r_a >= cap
+        self._T_a[full] += ps
+        self._r_a[full] -= ps
+        self._rs_a[full] = (self._rs_a[full] + ps) % cap
+        self._r_a += 1
+        self._seen_a += 1
 
     def get_cache_stats(self) -> Dict:
         """paged_pq_utils.py:898-939 (same keys) + the page-manager counters."""
         layer_stats = [{"layer_idx": l, "seen_tokens": self.seen_tokens[l], "residual_tokens": self.residualed_tokens[l],
                         "key_cache_tokens": self._T[l], "value_cache_tokens": self._T[l]} for l in range(self.layer_num)]
         mb = 1024 * 1024
-        cache_mb = sum(2 * self.bs * self.num_key_value_heads * t * self.M for t in self._T) / mb
+        cache_mb = float(2 * self.num_key_value_heads * self.M * self._T_a.sum()) / mb
         resid_mb = sum(c.numel() * c.element_size() for c in self.key_residual_cache + self.value_residual_cache) / mb
         return {"layer_stats": layer_stats, "total_memory_usage_mb": cache_mb + resid_mb,
                 "memory_breakdown": {"cache_memory_mb": cache_mb, "residual_memory_mb": resid_mb,

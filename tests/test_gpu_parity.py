@@ -1605,3 +1605,78 @@ def test_paged_cache_prefill_uses_hip_attention(env, oracle):
     kq = oracle.pq_decode(oracle.pq_encode(k, cents), cents).astype(np.float16)
     vq = oracle.pq_decode(oracle.pq_encode(v, cents), cents).astype(np.float16)
     _check(out.cpu().numpy(), _sdpa_ref_rows(q, kq, vq, list(range(n))), "distort_recent")
+
+
+def test_paged_cache_request_lifecycle_recycled_slot(env, oracle):
+    """Request lifecycle on the paged store (reference allocator dynamic_paged_pq_utils.py:137-241, cleanup
+    paged_pq_utils.py:1082-1118): batch slot 1 finishes, is released (pages back to the PageManager, lengths zeroed on the
+    device) and starts a NEW request with a shorter prompt while slot 0 keeps decoding; from then on the two requests have
+    different lengths, share every launch through the device-resident lengths, and flush their windows at different steps
+    (the flush launch skips the request whose window is not full).  Every checked step: both outputs vs the fp64 oracle on
+    each request's own history."""
+    torch, ops = env
+    from million_amd.pq_cache import PagedPQCache
+    bs, nh, nhk, d, M, C, ps, cap = 2, 8, 2, 128, 64, 256, 64, 128
+    rs = np.random.RandomState(123)
+    ck = rs.standard_normal((M, C, 2)).astype(np.float16)
+    cv = rs.standard_normal((M, C, 2)).astype(np.float16)
+    cache = PagedPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=1, d=d, page_size=ps,
+                         extended_residual_size=cap, max_tokens=1024, preallocate=False, device="cuda")
+    cache.set_cent(torch.from_numpy(ck).cuda(), torch.from_numpy(cv).cuda())
+    n0, n1, steps_a, steps_b = 200, 70, 100, 150
+    total = n0 + steps_a + steps_b + 8
+    K = rs.standard_normal((bs, nhk, total, d)).astype(np.float16)      # history of request (slot 0, slot 1 first request)
+    V = rs.standard_normal((bs, nhk, total, d)).astype(np.float16)
+    K2 = rs.standard_normal((1, nhk, total, d)).astype(np.float16)      # history of slot 1's second request
+    V2 = rs.standard_normal((1, nhk, total, d)).astype(np.float16)
+    Q = rs.standard_normal((steps_a + steps_b, bs, nh, 1, d)).astype(np.float16)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    cache.prefill(dev(Q[0]).expand(-1, -1, 1, -1).repeat(1, 1, n0, 1), dev(K[:, :, :n0]), dev(V[:, :, :n0]), 0)
+    used_before = cache.page_manager.get_stats()["allocated_pages"]
+    pol = [oracle.PagedPolicy(page_size=ps, residual=cap, prefill=n0) for _ in range(bs)]
+    hist = [(K[0:1], V[0:1]), (K[1:2], V[1:2])]
+    pos = [n0, n0]                                                        # next history row of each request
+
+    def check(i, out):
+        for b in range(bs):
+            Kb, Vb = hist[b]
+            T, r = pol[b].T, pol[b].r
+            kc, vc = oracle.pq_encode(Kb[:, :, :T], ck), oracle.pq_encode(Vb[:, :, :T], cv)
+            kres = np.zeros((1, nhk, cap, d), np.float16)
+            vres = np.zeros((1, nhk, cap, d), np.float16)
+            kres[:, :, :r], vres[:, :, :r] = Kb[:, :, T:T + r], Vb[:, :, T:T + r]
+            gold = oracle.decode_attn(Q[i, b:b + 1], kc, vc, ck, cv, kres, vres, r)
+            _check(out[b:b + 1], gold, f"step {i} request in slot {b} (T={T}, r={r})")
+
+    for i in range(steps_a + steps_b):
+        if i == steps_a:      # slot 1's request is done; a new one with a 70-token prompt takes the slot
+            cache.release(1)
+            st = cache.page_manager.get_stats()
+            assert st["allocated_pages"] < used_before + 8 and cache.lengths[0].cpu().numpy()[1].tolist() == [0, 0, 0, 0]
+            assert cache.lengths[0].cpu().numpy()[0, 0] == pol[0].T
+            cache.prefill_request(1, dev(Q[0, 1:2]).expand(-1, -1, 1, -1).repeat(1, 1, n1, 1), dev(K2[:, :, :n1]), dev(V2[:, :, :n1]), 0)
+            pol[1] = oracle.PagedPolicy(page_size=ps, residual=cap, prefill=n1)
+            hist[1] = (K2, V2)
+            pos[1] = n1
+        kn = np.concatenate([hist[b][0][:, :, pos[b]:pos[b] + 1] for b in range(bs)])
+        vn = np.concatenate([hist[b][1][:, :, pos[b]:pos[b] + 1] for b in range(bs)])
+        out = cache.decoding_with_pages(dev(Q[i]), dev(kn), dev(vn), 0, use_dev_lengths=True)
+        for b in range(bs):
+            pol[b].step()
+            pos[b] += 1
+        if i % 23 == 0 or i in (steps_a - 1, steps_a, steps_a + 1, steps_a + 57, steps_a + 58, steps_a + 59, steps_a + steps_b - 1):
+            torch.cuda.synchronize()
+            dl = cache.lengths[0].cpu().numpy()
+            assert [dl[b, :2].tolist() for b in range(bs)] == [[pol[b].T, pol[b].r] for b in range(bs)], (i, dl)
+            check(i, out.float().cpu().numpy().astype(np.float64))
+    # update(): the dequantise-then-attend path on pages, and cleanup()
+    cache.cleanup()
+    assert cache.page_manager.get_stats()["allocated_pages"] == 0 and not cache.lengths[0].cpu().numpy().any()
+    kf, vf = cache.update(dev(K[:, :, :90]), dev(V[:, :, :90]), 0)
+    np.testing.assert_array_equal(kf.cpu().numpy(), K[:, :, :90])
+    kf2, vf2 = cache.update(dev(K[:, :, 90:100]), dev(V[:, :, 90:100]), 0)
+    torch.cuda.synchronize()
+    want = np.concatenate([oracle.pq_decode(oracle.pq_encode(K[:, :, :90], ck), ck).astype(np.float16), K[:, :, 90:100]], axis=2)
+    np.testing.assert_array_equal(kf2.cpu().numpy(), want)
+    want_v = np.concatenate([oracle.pq_decode(oracle.pq_encode(V[:, :, :90], cv), cv).astype(np.float16), V[:, :, 90:100]], axis=2)
+    np.testing.assert_array_equal(vf2.cpu().numpy(), want_v)

@@ -278,3 +278,39 @@ def test_formats_against_reference_written_files(golden_dir):
     np.testing.assert_array_equal(vc.numpy(), np.asarray(pq["val"], dtype=np.float32))
     k16, _ = F.load_centroids(golden_dir, pq["M"], pq["nbits"])      # default: the model dtype the caches take
     assert k16.dtype == torch.float16 and k16.shape == (4, 4, 2)
+
+
+def test_paged_cache_host_lifecycle_on_cpu():
+    """Host half of the request lifecycle (no kernels): on-demand page assignment per request, release() returns exactly the
+    released slot's pages to the PageManager and zeroes its lengths, the other slot keeps its pages; the per-layer views
+    (cache._T[l] ...) read request 0 and write every request."""
+    import numpy as np
+    from million_amd.pq_cache import PagedPQCache
+    c = PagedPQCache(bs=2, nh=8, num_key_value_heads=2, M=64, layer_num=3, d=128, page_size=64, extended_residual_size=128,
+                     max_tokens=1024, preallocate=False, device="cpu")
+    assert c.page_manager.get_stats()["allocated_pages"] == 0
+    c._assign_pages(1, 5)                       # both requests of layer 1: 5 pages x 2 kv heads each
+    c._assign_pages(2, 3, b=1)
+    assert c.page_manager.get_stats()["allocated_pages"] == 2 * 2 * 5 + 2 * 3
+    ids = c.page_ids[1].numpy()
+    assert len(set(ids[:, :, :5].ravel().tolist())) == 20
+    c._T_a[1] = [300, 200]
+    c._r_a[1] = [5, 128]
+    assert c._T[1] == 300 and c.residualed_tokens[1] == 5 and not c._lockstep(1) and c._lockstep(0)
+    assert c.next_step_flushes(1) and not c.next_step_flushes(0)
+    kept = set(ids[0, :, :5].ravel().tolist())
+    c.release(1)
+    st = c.page_manager.get_stats()
+    assert st["allocated_pages"] == 10 and set(c.page_manager.allocated_pages) == kept
+    assert c._T_a[1].tolist() == [300, 0] and c._r_a[1].tolist() == [5, 0] and c._pages_a[:, 1].tolist() == [0, 0, 0]
+    c._T[0] = 64                                 # legacy per-layer write: every request
+    assert c._T_a[0].tolist() == [64, 64]
+    st0 = c.host_state()
+    c.set_host_state(([7] * 3, [1, 2, 3], st0[2], st0[3]))
+    assert c._seen_a.tolist() == [[7, 7]] * 3 and c._r_a.tolist() == [[1, 1], [2, 2], [3, 3]] and c._T_a[1].tolist() == [300, 0]
+    c.set_host_state(st0)
+    c._r_a[:] = [[127, 128], [0, 0], [128, 128]]
+    c._T_a[:] = 0
+    c.note_replayed_step()
+    assert c._r_a.tolist() == [[128, 65], [1, 1], [65, 65]] and c._T_a.tolist() == [[0, 64], [0, 0], [64, 64]]
+    assert c._rs_a.tolist() == [[0, 64], [0, 0], [64, 64]]

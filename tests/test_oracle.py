@@ -175,3 +175,19 @@ def test_cache_policies(oracle):
     seq = [pg.step() for _ in range(300)]
     assert seq[127] == (1000, 128) and seq[128] == (1064, 65) and seq[191] == (1064, 128) and seq[192] == (1128, 65)
     assert all(T + r == 1000 + i + 1 for i, (T, r) in enumerate(seq))
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """oracle/pq_oracle.c compiled with -fsanitize=address,undefined and driven by oracle/selftest.c over the edge shapes
+    (T = 0, r = 0, one vector, uint16 codes, ragged splits): no report, invariants hold (CPU build only)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1] / "oracle"
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "selftest"
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-o", str(exe), str(root / "selftest.c"), str(root / "pq_oracle.c"), "-lm"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
