@@ -59,13 +59,12 @@ def _check_common(name, query, key_cents, value_cents, key_residuals, value_resi
 def _make_flash_decoding(name, Ns, Lt, d, M, C):
     def flash_decoding(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals,
                        r, partial_out_buffer, partial_lse_buffer):
-        _check_common(name, query, key_cents, value_cents, key_residuals, value_residuals, r, d, M, C)
-        if key_codes.dtype != torch.uint8 or value_codes.dtype != torch.uint8:
-            raise RuntimeError(f"{name}: expected scalar type Byte for codes")
-        kp = _ops.prepare_cents(key_cents)
-        vp = kp if value_cents is key_cents else _ops.prepare_cents(value_cents)
-        return _ops.pq_decode_attn(query.contiguous(), key_codes, value_codes, kp, vp, key_residuals, value_residuals,
-                                   int(r), M=M, C=C)
+        def check():      # run when the call's signature (shapes, strides, dtypes, codebook objects) is new: ops.decode_attn_planned
+            _check_common(name, query, key_cents, value_cents, key_residuals, value_residuals, r, d, M, C)
+            if key_codes.dtype != torch.uint8 or value_codes.dtype != torch.uint8:
+                raise RuntimeError(f"{name}: expected scalar type Byte for codes")
+        return _ops.decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals,
+                                        r, M=M, C=C, check=check)
 
     flash_decoding.__name__ = name
     flash_decoding.__doc__ = (f"(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals, r, "
@@ -78,19 +77,17 @@ def _make_paged_v(name, Ns, Lt, d, M, C):
     def flash_decoding_paged_v(query, key_codes, key_cents, key_residuals, value_page_ids, value_page_pool,
                                value_cents, value_residuals, r, n_pages, page_size, partial_out_buffer,
                                partial_lse_buffer):
-        _check_common(name, query, key_cents, value_cents, key_residuals, value_residuals, r, d, M, C)
-        if value_page_pool.dim() != 3 or value_page_pool.shape[1] != M or value_page_pool.shape[2] != page_size:
-            raise RuntimeError(f"{name}: value_page_pool must be (max_pages, {M}, {page_size})")
-        if value_page_ids.dim() != 3 or value_page_ids.shape[2] < n_pages:
-            raise RuntimeError(f"{name}: value_page_ids must be (bs, nh_k, >= n_pages)")
-        nk = key_codes.shape[2]
-        if nk > n_pages * page_size:
-            raise RuntimeError(f"{name}: {nk} key tokens but only {n_pages} value pages of {page_size}")
-        kp = _ops.prepare_cents(key_cents)
-        vp = kp if value_cents is key_cents else _ops.prepare_cents(value_cents)
-        return _ops.pq_decode_attn(query.contiguous(), key_codes, value_page_pool, kp, vp, key_residuals,
-                                   value_residuals, int(r), M=M, C=C, n_tokens=nk,
-                                   v_page_ids=value_page_ids.contiguous(), page_size=int(page_size))
+        def check():      # see _make_flash_decoding
+            _check_common(name, query, key_cents, value_cents, key_residuals, value_residuals, r, d, M, C)
+            if value_page_pool.dim() != 3 or value_page_pool.shape[1] != M or value_page_pool.shape[2] != page_size:
+                raise RuntimeError(f"{name}: value_page_pool must be (max_pages, {M}, {page_size})")
+            if value_page_ids.dim() != 3 or value_page_ids.shape[2] < n_pages:
+                raise RuntimeError(f"{name}: value_page_ids must be (bs, nh_k, >= n_pages)")
+        if key_codes.shape[2] > n_pages * page_size:
+            raise RuntimeError(f"{name}: {key_codes.shape[2]} key tokens but only {n_pages} value pages of {page_size}")
+        return _ops.decode_attn_planned(query, key_codes, value_page_pool, key_cents, value_cents, key_residuals,
+                                        value_residuals, r, M=M, C=C, v_page_ids=value_page_ids, page_size=int(page_size),
+                                        check=check)
 
     flash_decoding_paged_v.__name__ = name
     flash_decoding_paged_v.__doc__ = ("(query, key_codes, key_cents, key_residuals, value_page_ids, value_page_pool, "

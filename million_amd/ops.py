@@ -19,7 +19,8 @@ _prep_cache = {}
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's current stream: ~0.2 us (torch.cuda.current_stream().cuda_stream builds a Stream object: ~1.5 us)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _ptr(t: Optional[torch.Tensor]) -> int:
@@ -103,7 +104,7 @@ def pq_encode_into(X: torch.Tensor, cents: torch.Tensor, dst: torch.Tensor, *, l
     lib = L.load()
     L.check(lib.million_pq_encode(ctypes.byref(desc), X.data_ptr(), cents.data_ptr(), dst.data_ptr(),
                                   _ptr(page_ids), _stream()), "million_pq_encode")
-    _vshadow.pop(id(dst), None)      # written behind torch's back (no version bump): drop a transposed shadow of dst
+    _vshadow_drop(dst)
 
 
 def pq_decode(codes: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
@@ -202,12 +203,20 @@ _vshadow: "dict[int, tuple]" = {}
 _VSHADOW_MAX = 128
 
 
+def _base_of(t: torch.Tensor) -> torch.Tensor:
+    b = t._base
+    return t if b is None else b
+
+
 def _v_pages_of(v_codes: torch.Tensor, n_tokens: int) -> torch.Tensor:
-    key = id(v_codes)
-    sig = (v_codes._version, n_tokens, tuple(v_codes.shape), v_codes.stride(), v_codes.data_ptr())
+    """Keyed on the BASE tensor of v_codes (weak reference: a new tensor at a recycled address never hits) + the shared
+    version counter + the view's geometry: `store[:, :, :T]` taken afresh on every call (what DynamicPQCache.decoding(
+    fused=False) and the reference's PagedPQCache pass) finds the pages made for the previous view of the same store."""
+    base = _base_of(v_codes)
+    key = id(base)
+    sig = (v_codes._version, n_tokens, v_codes.shape, v_codes.stride(), v_codes.data_ptr())
     hit = _vshadow.get(key)
-    if hit is not None and hit[0]() is v_codes and hit[1] == sig:
-        _vshadow[key] = _vshadow.pop(key)          # most recently used last
+    if hit is not None and hit[0]() is base and hit[1] == sig:
         return hit[2]
     pages = transpose_v_codes(v_codes, n_tokens)
     for k in [k for k, v in _vshadow.items() if v[0]() is None]:
@@ -215,8 +224,13 @@ def _v_pages_of(v_codes: torch.Tensor, n_tokens: int) -> torch.Tensor:
     while len(_vshadow) >= _VSHADOW_MAX:
         del _vshadow[next(iter(_vshadow))]
     _vshadow.pop(key, None)
-    _vshadow[key] = (weakref.ref(v_codes), sig, pages)
+    _vshadow[key] = (weakref.ref(base), sig, pages)
     return pages
+
+
+def _vshadow_drop(dst: torch.Tensor) -> None:
+    """dst was written behind torch's back (a kernel of this library: no version bump): forget a transposed shadow of it."""
+    _vshadow.pop(id(_base_of(dst)), None)
 
 
 def attn_workspace(desc: L.AttnDesc, device: torch.device) -> torch.Tensor:
@@ -383,6 +397,103 @@ def prefill_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: b
     desc.o_stride_b, desc.o_stride_h, desc.o_stride_n = out.stride(0), out.stride(1), out.stride(2)
     L.check(L.load().million_prefill_attn(ctypes.byref(desc), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _stream()),
             "million_prefill_attn")
+    return out
+
+
+# ---- the reference's 10- / 13-argument calls, steady state ----------------------------------------------------------
+# An unchanged reference harness calls `bindings.*` eagerly, 32 times per token (pq_utils.py:61-94); its boundary is a
+# compiled pybind11 module (bindings.template.cpp:11-63).  pq_decode_attn above validates everything and rebuilds the
+# descriptor on every call (~21 us of Python per call for a ~8 us kernel).  decode_attn_planned keeps, per call signature
+# (shapes, strides, dtypes, device), the validated descriptor and workspace of the first call: a steady-state call is a
+# signature tuple, a dict lookup, two descriptor fields, the data pointers and ONE ctypes call.
+class _Plan:
+    __slots__ = ("desc", "desc_ref", "ws", "ws_ptr", "ws_bytes", "v_dense", "kc", "kver", "kprep", "vc", "vver", "vprep")
+
+
+_plans: "dict[tuple, _Plan]" = {}
+
+
+def _plan_cents(plan: _Plan, key_cents, value_cents, check):
+    if plan.kc() is not key_cents or plan.kver != key_cents._version:
+        if check is not None:
+            check()                      # a codebook the plan has not seen: the caller's shape / dtype checks again
+        plan.kprep, plan.kc, plan.kver = prepare_cents(key_cents), weakref.ref(key_cents), key_cents._version
+    if value_cents is key_cents:
+        return plan.kprep, plan.kprep
+    if plan.vc is None or plan.vc() is not value_cents or plan.vver != value_cents._version:
+        if check is not None:
+            check()
+        plan.vprep, plan.vc, plan.vver = prepare_cents(value_cents), weakref.ref(value_cents), value_cents._version
+    return plan.kprep, plan.vprep
+
+
+def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals, r, *, M, C,
+                        v_page_ids=None, page_size=0, check=None):
+    """The reference's production call (row-major K codes; V row-major, or a transposed page pool with page ids) with the
+    per-call host work cut to the minimum.  Falls to pq_decode_attn (full validation) on the first call of a signature and
+    for anything unusual (non-contiguous query, shapes off the MFMA kernels, empty store).  check: the caller's own argument
+    checks, run on those slow-path calls only (a signature that passed them once passes them again: shapes, strides and
+    dtypes of every tensor are in the signature; the codebooks are identified by object and version)."""
+    T = key_codes.shape[2]
+    paged = v_page_ids is not None
+    stream = _stream()      # part of the signature: the workspace of a plan belongs to one (device, stream)
+    sig = (stream, query.shape, query.dtype, query.is_contiguous(), key_codes.shape[1], key_codes.stride(), key_codes.dtype,
+           value_codes.shape[1:] if paged else value_codes.stride(), value_codes.dtype,
+           key_residuals.shape, key_residuals.stride(), key_residuals.dtype, value_residuals.shape, value_residuals.stride(),
+           value_residuals.dtype,
+           (v_page_ids.shape, v_page_ids.dtype, v_page_ids.is_contiguous(), page_size) if paged else None,
+           query.device.index, M, C)
+    plan = _plans.get(sig)
+    if plan is None:
+        if check is not None:
+            check()
+        kp = prepare_cents(key_cents)
+        vp = kp if value_cents is key_cents else prepare_cents(value_cents)
+        out = pq_decode_attn(query.contiguous(), key_codes, value_codes, kp, vp, key_residuals, value_residuals, int(r), M=M, C=C,
+                             **(dict(n_tokens=T, v_page_ids=v_page_ids.contiguous(), page_size=int(page_size)) if paged else {}))
+        d = query.shape[3]
+        fast_shape = (C in (128, 256) and d in (64, 128) and M in (16, 32, 64) and T > 0 and query.is_contiguous()
+                      and key_codes.is_cuda and (not paged or v_page_ids.is_contiguous()))
+        if fast_shape and len(_plans) < 256:      # the call above has validated this signature
+            plan = _Plan()
+            if paged:
+                plan.desc = make_attn_desc(query, key_residuals, nh_k=key_residuals.shape[1], M=M, C=C, n_tokens=T, r=int(r),
+                                           k_paged=False, v_paged=True, page_size=int(page_size), n_pages_cap=v_page_ids.shape[2],
+                                           page_ids_i64=v_page_ids.dtype == torch.int64, k_codes=key_codes)
+            else:
+                plan.desc = make_attn_desc(query, key_residuals, nh_k=key_residuals.shape[1], M=M, C=C, n_tokens=T, r=int(r),
+                                           k_paged=False, v_paged=True, page_size=64, n_pages_cap=(T + 63) // 64,
+                                           k_codes=key_codes, v_pages_dense=True)
+            plan.desc_ref = ctypes.byref(plan.desc)
+            plan.ws = attn_workspace(plan.desc, query.device)
+            plan.ws_ptr, plan.ws_bytes = plan.ws.data_ptr(), plan.ws.numel()
+            plan.v_dense = not paged
+            plan.kc, plan.kver, plan.kprep = weakref.ref(key_cents), key_cents._version, kp
+            plan.vc, plan.vver, plan.vprep = (None, 0, kp) if value_cents is key_cents else (weakref.ref(value_cents), value_cents._version, vp)
+            _plans[sig] = plan
+        return out
+    if T <= 0:
+        raise RuntimeError("decode_attn_planned: empty code store")      # (never cached: fast_shape needs T > 0)
+    r = int(r)
+    if not 0 <= r <= key_residuals.shape[2]:
+        raise RuntimeError(f"pq_decode_attn: r={r} outside [0, {key_residuals.shape[2]}]")
+    kp, vp = _plan_cents(plan, key_cents, value_cents, check)
+    desc = plan.desc
+    desc.n_tokens, desc.r = T, r
+    if plan.v_dense:
+        desc.n_pages_cap = (T + 63) // 64
+        v_ptr, ids_ptr = _v_pages_of(value_codes, T).data_ptr(), 0
+    else:
+        if v_page_ids.shape[2] * page_size < T:
+            raise RuntimeError("pq_decode_attn: page table shorter than the key codes")
+        v_ptr, ids_ptr = value_codes.data_ptr(), v_page_ids.data_ptr()
+    ws_ptr, ws_bytes = plan.ws_ptr, plan.ws_bytes
+    out = torch.empty_like(query)
+    rc = L.load().million_pq_decode_attn(plan.desc_ref, query.data_ptr(), key_codes.data_ptr(), v_ptr, 0, ids_ptr, kp.data_ptr(),
+                                         vp.data_ptr(), key_residuals.data_ptr(), value_residuals.data_ptr(), out.data_ptr(),
+                                         ws_ptr, ws_bytes, stream)
+    if rc:
+        L.check(rc, "million_pq_decode_attn")
     return out
 
 

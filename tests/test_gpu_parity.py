@@ -1064,6 +1064,22 @@ def test_rowmajor_v_shadow_reuse_and_invalidation(env, oracle):
     del v2
     call(t["v_codes"])
     assert len(ops._vshadow) == 1 + sum(1 for v in ops._vshadow.values() if v[0]() is None)
+    # fresh VIEWS of one store on every call (what DynamicPQCache.decoding(fused=False) and the reference's PagedPQCache
+    # pass: store[:, :, :T]) hit the pages made for the previous view: the shadow is keyed on the base tensor
+    ops._vshadow.clear()
+    store = torch.zeros(1, 8, 4096, 64, dtype=torch.uint8, device="cuda")
+    store[:, :, :3000] = t["v_codes"]
+    o4 = call(store[:, :, :3000])
+    pages4 = ops._vshadow[id(store)][2]
+    o5 = call(store[:, :, :3000])
+    assert ops._vshadow[id(store)][2] is pages4 and len(ops._vshadow) == 1
+    _check(o4.cpu().numpy(), oracle.decode_attn(**c2), "view, first call")
+    _check(o5.cpu().numpy(), oracle.decode_attn(**c2), "view, second call (hit through the base)")
+    # a kernel of this library writing into a view of the store (no version bump) drops the store's shadow
+    from million_amd import _lib as L
+    X = torch.randn(1, 8, 64, 128, device="cuda").half()
+    ops.pq_encode_into(X, t["v_cents"], store[:, :, :3064], token_start=3000, n=64)
+    assert id(store) not in ops._vshadow
 
 
 def test_harness_pq_step_attention_against_oracle(env, oracle):
