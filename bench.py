@@ -70,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--force-generic", action="store_true", help="A/B: use the generic LUT kernel")
     ap.add_argument("--kernel-policy", type=int, default=0, help="A/B knob passed to million_set_force_generic")
     ap.add_argument("--roofline-launches", type=int, default=256)
+    ap.add_argument("--inline-flush", action="store_true", help="A/B: flush each layer's window in front of its attention launch instead of ahead on a side stream")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end TPOT / TTFT record (N = 1 only; ~1-2 min)")
     ap.add_argument("--e2e-cap-s", type=float, default=240.0, help="no end-to-end backend is started later than this many seconds into the e2e leg")
     ap.add_argument("--dry-cpu", action="store_true",
@@ -176,6 +177,8 @@ def main():
     outs = [torch.empty(bs, nh, 1, d, device=dev, dtype=torch.float16) for _ in range(layers)]
 
     def step_eager(use_dl):
+        if not args.inline_flush and cache.next_step_flushes():
+            cache.flush_ahead(use_dev_lengths=use_dl)      # all layers' flushes on a side stream, joined layer by layer
         for l in range(layers):
             cache.decoding_with_pages(q[l], kn[l], vn[l], l, out=outs[l], use_dev_lengths=use_dl)
 
@@ -220,6 +223,21 @@ def main():
     # for the record: one whole flush period (64 steps = 63 plain + 1 flush), the steady-state mix
     elapsed64 = sharding.timed_steps(counted_step, 64, torch.cuda.synchronize, dist if world > 1 else None)
     value64, ms64 = sharding.aggregate_throughput(bs, 64, elapsed64, world)
+    # and the two kinds of step apart (HIP events around every step of another period): what a flush step costs
+    step_ev, step_is_flush = [], []
+    for _ in range(64):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step_is_flush.append(cache.next_step_flushes())
+        a.record()
+        one_step()
+        b.record()
+        step_ev.append((a, b))
+    torch.cuda.synchronize()
+    step_ms = [a.elapsed_time(b) for a, b in step_ev]
+    plain_ms = [t for t, f in zip(step_ms, step_is_flush) if not f]
+    flush_ms = [t for t, f in zip(step_ms, step_is_flush) if f]
+    plain_step_ms = sorted(plain_ms)[len(plain_ms) // 2] if plain_ms else None
+    flush_step_ms = sum(flush_ms) / len(flush_ms) if flush_ms else None
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream ----
     # `achieved` uses the average launch duration over a region of nl back-to-back launches between ONE pair of events
@@ -293,8 +311,12 @@ def main():
                                              f"per-GPU batch {bs} (BASELINE configs[3] = 16 requests over 8 GPUs): the like-for-like "
                                              f"1-GPU base is `bench.py --gpus 1 --batch-per-gpu {bs}`, not the default configs[2] line"),
                        "flush_steps_in_timed_region": flushes_timed,
+                       "flush": "in-line" if args.inline_flush else "ahead: all layers' flush launches on a side stream, each layer's attention waits for its own",
                        "steady_state_64_steps": {"value": round(value64, 2), "ms_per_step": round(ms64, 4),
                                                  "note": "one whole flush period (63 plain steps + 1 flush step)"},
+                       "plain_step_ms": round(plain_step_ms, 4) if plain_step_ms else None,
+                       "flush_step_ms": round(flush_step_ms, 4) if flush_step_ms else None,
+                       "flush_step_over_plain_step": round(flush_step_ms / plain_step_ms, 3) if plain_step_ms and flush_step_ms else None,
                        "launch": "eager" if args.no_graph else "hipGraph replay",
                        "kernel": "generic-LUT" if args.force_generic else ("auto" if not args.kernel_policy else f"policy{args.kernel_policy}")},
             "roofline": {"bound": "hbm", "kernel": "fused decode attention (one launch per layer-call)",

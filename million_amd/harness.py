@@ -179,11 +179,18 @@ class PQBackend:
             for l in range(L):
                 self.cache._sync_lengths(l)
         self.use_dev_lengths = False
+        self.flush_ahead = True
         self.timers = NO_TIMERS
 
     def prefill(self, layer, q, k, v):
         with self.timers("prefill_encode+sdpa"):
             return self.cache.prefill(q, k, v, layer)
+
+    def begin_step(self):
+        """Start of a decode step: full windows of all layers are flushed ahead on the cache's side stream (not with the
+        section timers on: they want the flush as a section of its own)."""
+        if self.flush_ahead and self.timers is NO_TIMERS and self.cache.next_step_flushes():
+            self.cache.flush_ahead(use_dev_lengths=self.use_dev_lengths)
 
     def attend(self, layer, q, k, v):
         if self.timers is not NO_TIMERS and self.cache.residualed_tokens[layer] >= self.cache.extended_residual_size:
@@ -241,6 +248,8 @@ class LlamaShapeDecoder:
         s, tm = self.s, self.timers
         bs = tokens.shape[0]
         x = self.embed[tokens]                                           # (bs, hidden)
+        if hasattr(backend, "begin_step"):
+            backend.begin_step()
         for l, L in enumerate(self.layers):
             hN = self._rms(x, L["n1"])
             with tm("qkv_proj"):

@@ -384,6 +384,7 @@ class PagedPQCache(_CacheBase):
         self._seen_a, self._r_a, self._T_a, self._rs_a, self._pages_a = zi(), zi(), zi(), zi(), zi()
         self._host_pids = [[[[] for _ in range(nk)] for _ in range(self.bs)] for _ in range(self.layer_num)]
         self._ws = None
+        self._side, self._flush_events = None, {}
         if self.preallocate:
             for l in range(self.layer_num):
                 for b in range(self.bs):
@@ -553,13 +554,40 @@ class PagedPQCache(_CacheBase):
             self._r_a[layer_idx, b] -= ps
             self._rs_a[layer_idx, b] = (self._rs_a[layer_idx, b] + ps) % cap
 
+    def flush_ahead(self, use_dev_lengths=False):
+        """Flush the full windows of ALL layers now, on a side stream, instead of layer by layer in front of each layer's
+        attention: a layer's window rows and lengths do not depend on the current step's computation, so the 32 flush
+        launches of a flush step (9.5 us each, dependent chains of small loads) run beside the attention launches of the
+        layers before them; decoding_with_pages(layer) then only waits for its layer's flush event.  Call it at the start of
+        a decode step (next_step_flushes() says when); every layer must then be decoded in this step (the side stream is
+        joined layer by layer - also inside a hipGraph capture, where this becomes a fork / join of graph branches).
+        Results are identical to the in-line flush."""
+        cap = self.extended_residual_size
+        todo = [l for l in range(self.layer_num) if (self._r_a[l] >= cap).any()]
+        if not todo:
+            return
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._flush_events = {}
+        self._side.wait_stream(main)      # fork: behind everything this stream has queued (the previous step's appends)
+        with torch.cuda.stream(self._side):
+            for l in todo:
+                self.flush_to_pages(l, use_dev_lengths=use_dev_lengths)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._flush_events[l] = ev
+
     def decoding_with_pages(self, query_states, key_states, value_states, layer_idx, out=None, use_dev_lengths=False):
         """One decode step of one layer (paged_pq_utils.py:341-386): flush if the window is full, append the
         new token's K/V row, fused attention over pages + window.  With use_dev_lengths=True every length
         is read on the device (the host mirror is still advanced), which makes the call graph-capturable and lets
         requests of different lengths share the launch."""
         cap = self.extended_residual_size
-        if (self._r_a[layer_idx] >= cap).any():                                          # :359-361
+        ev = self._flush_events.pop(layer_idx, None) if getattr(self, "_side", None) is not None else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)                                   # flushed ahead on the side stream
+        elif (self._r_a[layer_idx] >= cap).any():                                        # :359-361
             self.flush_to_pages(layer_idx, use_dev_lengths=use_dev_lengths)
         lock = self._lockstep(layer_idx)
         if not lock and not use_dev_lengths:
