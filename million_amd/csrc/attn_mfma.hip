@@ -31,6 +31,10 @@
 
 #include "common.h"
 
+#ifndef MILLION_EXP
+#define MILLION_EXP 0      // development A/B switches (tools/ab_build.py); 0 in the product build
+#endif
+
 namespace million {
 
 typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
@@ -1403,6 +1407,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
     UNIT_REQ(0, 0)
     UNIT_REQ(1, 1)
+    // (Round 3, tools/ab_build.py: units 2 and 3 requested here too - all four ring slots up front - 19.5 us instead of 16.8 at
+    // one request, 25.2 vs 24.0 at two; right behind the codebook barrier: 18.1 / 23.9.  The CU's request queue is in order:
+    // what is asked for before the codebooks are in LDS delays the barrier every wave waits at.)
     STAMP(7);
     {
         v4u *ld = (v4u *)smem;
