@@ -433,8 +433,10 @@ __device__ __forceinline__ void value_unit(const v4u (&vc)[1], const float (&pr)
 }
 
 // ---- residual window -------------------------------------------------------------------------------
-// The window rows j = split, split + nsplit, ... < r of a split are dealt to its waves round-robin: wave w
-// owns list entries idx = w + 8*i, i < kResRows, as ONE 16-row MFMA tile that rides along with the code
+// The window rows j = split, split + nsplit, ... < r of a split are dealt to its waves in runs of kResRows: wave w
+// owns list entries idx = 16 w + i, i < kResRows (round 3; rounds 1-2 dealt them round-robin, idx = w + 8 i: with 4-7
+// rows per split that made 4-7 waves load a whole 16-row tile - 12 requests each in the kernel's front - for ONE row;
+// now the older, faster wave 0 takes them all), as ONE 16-row MFMA tile that rides along with the code
 // units of the first group: scores with A = the fp16 K rows themselves, values with B = the fp16 V rows
 // (k = 16 rows, cols = 32 subspaces; even / odd dims by v_perm like the looked-up centroids).  Rows past the
 // list re-read the wave's first row and are masked to -inf.
@@ -446,7 +448,7 @@ struct ResTile {
 // Row pointer of list entry idx (clamped to the wave's first entry, which exists when the tile is used).
 __device__ __forceinline__ long long res_row_off(const AttnParams &p, int idx, int wave, int rcnt, int split, int rstart,
                                                  int r_old, bool &is_new) {
-    const int idc = idx < rcnt ? idx : wave;
+    const int idc = idx < rcnt ? idx : kResRows * wave;
     const int j = split + idc * p.nsplit;
     int row = rstart + j;
     row = row >= p.rcap ? row - p.rcap : row;          // rstart, j < rcap: one wrap at most
@@ -460,7 +462,7 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
     const int q4 = lane >> 4, c16 = lane & 15, h = lane >> 5, c32 = lane & 31;
     {
         bool is_new;
-        const long long off = res_row_off(p, wave + kNW * c16, wave, rcnt, split, rstart, r_old, is_new);
+        const long long off = res_row_off(p, kResRows * wave + c16, wave, rcnt, split, rstart, r_old, is_new);
         const f16 *kp = (is_new ? p.k_new + (long long)bh * 128 : kr + off) + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
@@ -468,7 +470,7 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         bool is_new;
-        const long long off = res_row_off(p, wave + kNW * (8 * h + j), wave, rcnt, split, rstart, r_old, is_new);
+        const long long off = res_row_off(p, kResRows * wave + 8 * h + j, wave, rcnt, split, rstart, r_old, is_new);
         if (MS == 64) {      // tile (n, kk): dim 2*(32n + c32) + kk
             const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 2 * c32;
             t.v[0][j] = *(const unsigned *)vp;
@@ -492,7 +494,7 @@ __device__ __forceinline__ void score_res_tile(const ResTile &t, const v8f16 (&q
         D = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, t.k[s]), qb[s], D, 0, 0, 0);
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho)
-        sc[rho] = (wave + kNW * (4 * q4 + rho)) < rcnt ? D[rho] * scale_log2e : -INFINITY;
+        sc[rho] = (kResRows * wave + 4 * q4 + rho) < rcnt ? D[rho] * scale_log2e : -INFINITY;
 }
 
 // O += P (heads x 16 rows) * V rows.  pr[rho] = probability of row 4*q' + rho for the head of this lane's column.
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
     //      round-robin; this wave's tile is requested BEFORE the code bytes: the counted wait in front of the
     //      K-codebook store then covers these few L2-resident rows, not the HBM-bound code loads behind them ----
     const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
-    const bool has_res = wave < rcnt;                  // wave-uniform
+    const bool has_res = kResRows * wave < rcnt;       // wave-uniform
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
     ResTile rt;
@@ -1366,7 +1368,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 
     // ---- residual window rows of this split, dealt to the waves round-robin (see load_res_tile) ----
     const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
-    const bool has_res = wave < rcnt;
+    const bool has_res = kResRows * wave < rcnt;
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
     ResTile rt;
