@@ -1411,7 +1411,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     UNIT_REQ(1, 1)
     // (Round 3, tools/ab_build.py: units 2 and 3 requested here too - all four ring slots up front - 19.5 us instead of 16.8 at
     // one request, 25.2 vs 24.0 at two; right behind the codebook barrier: 18.1 / 23.9.  The CU's request queue is in order:
-    // what is asked for before the codebooks are in LDS delays the barrier every wave waits at.)
+    // what is asked for before the codebooks are in LDS delays the barrier every wave waits at.  Also without effect (+-0.15 us
+    // at 1 and 2 requests and at 128K): the query rows through LDS (one request instead of 32 per workgroup), the V bytes of
+    // units 0-1 requested behind the barrier, s_setprio 1 for waves 4-7 over the last one, two or three blocks.)
     STAMP(7);
     {
         v4u *ld = (v4u *)smem;
