@@ -90,6 +90,26 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float lane_bcast(float x, int lane_const) {       // v_readlane -> SGPR operand
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane_const));
 }
+// Rescale of the value accumulators when a head's softmax reference moves.  alpha of head g sits in lane g; O rows (32x32
+// tile, register 4 j + rho): lanes < 32 hold head 8 j + rho, lanes >= 32 head 8 j + 4 + rho; j = 1 only exists for groups
+// of more than 8 query heads (wave-uniform branch).  Rows of heads >= G are scaled by whatever their idle column holds:
+// they are never read.  One ds_bpermute per register row (no SGPRs: 16 v_readlane results spilled scalar registers in
+// the streaming loop).
+__device__ __forceinline__ void rescale_heads(v16f32 (&O)[2][2], float alpha, int G, int lane) {
+    const int sel = lane < 32 ? 0 : 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && G <= 8) break;
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            const float f = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel + 4 * (8 * j + rho), __builtin_bit_cast(int, alpha)));
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) O[n][kk][4 * j + rho] *= f;
+        }
+    }
+}
 __device__ __forceinline__ v8f16 as_v8f16(unsigned a, unsigned b, unsigned c, unsigned d) {
     v4u t = {a, b, c, d};
     return __builtin_bit_cast(v8f16, t);
@@ -671,26 +691,28 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         const bool all_here = __all(cen_v == tail_xcc() + 1u);
         if (lane == 0) tl[3] = all_here ? 1 : 0;
     }
-    const int wstride = G * 128 + 2 * kMaxG;              // floats per wave
+    const int wstride = G * 128 + 2 * kMaxGMfma;          // floats per wave (G = 16: 65 KiB for the 8 waves, the dead tables' space)
     float *scr_l = (float *)smem;
     float *mine = scr_l + wave * wstride;
     {
         const bool hi = lane >= 32;
         const int c32 = lane & 31;
 #pragma unroll
-        for (int rho = 0; rho < 4; ++rho) {
-            const int g = hi ? 4 + rho : rho;
-            if (g < G) {
+        for (int j = 0; j < 2; ++j)                      // tile rows 8 j + 4 hi + rho = register 4 j + rho; j = 1: groups above 8 heads
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+            for (int rho = 0; rho < 4; ++rho) {
+                const int g = 8 * j + (hi ? 4 + rho : rho);
+                if (g < G) {
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        mine[g * 128 + (MS == 64 ? 2 * (32 * n + c32) + kk : 4 * c32 + 2 * n + kk)] = O[n][kk][rho];
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+                            mine[g * 128 + (MS == 64 ? 2 * (32 * n + c32) + kk : 4 * c32 + 2 * n + kk)] = O[n][kk][4 * j + rho];
+                }
             }
-        }
         if (lane < G) {                                  // lane g: row q' = 0, col g
             mine[G * 128 + lane] = m_run;
-            mine[G * 128 + kMaxG + lane] = l_run;
+            mine[G * 128 + kMaxGMfma + lane] = l_run;
         }
     }
     __syncthreads();
@@ -710,7 +732,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
             for (int w = 0; w < kNW; ++w) {
                 mw[w] = scr_l[w * wstride + G * 128 + g];
                 vw[w] = *(const v4f32 *)(scr_l + w * wstride + 4 * q);
-                lw[w] = scr_l[w * wstride + G * 128 + kMaxG + g];
+                lw[w] = scr_l[w * wstride + G * 128 + kMaxGMfma + g];
             }
             float Mx = mw[0];
 #pragma unroll
@@ -992,14 +1014,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
         const float m_safe = m_new > -INFINITY ? m_new : 0.f;                                                      \
         const float alpha = fast_exp2(m_run - m_safe);                                                             \
         if (!(FIRST) && __any(m_new > m_run && m_run > -INFINITY)) {                                               \
-            /* alpha of head g sits in lane g; O rows: lanes < 32 hold heads rho, lanes >= 32 heads 4 + rho */     \
-            _Pragma("unroll") for (int rho = 0; rho < 4; ++rho) {                                                  \
-                const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;                                         \
-                const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;                                 \
-                const float f = lane < 32 ? flo : fhi;                                                             \
-                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                      \
-                    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;                           \
-            }                                                                                                      \
+            rescale_heads(O, alpha, G, lane);                                                                      \
         }                                                                                                          \
         float ls = 0.f;                                                                                            \
         _Pragma("unroll") for (int k = 0; k < kRing; ++k)                                                          \
@@ -1129,17 +1144,7 @@ __device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, flo
     const float m_safe = m_new > -INFINITY ? m_new : 0.f;
     const float alpha = fast_exp2(m_run - m_safe);
     if (__any(m_new > m_run && m_run > -INFINITY)) {
-        // alpha of head g sits in lane g; O rows: lanes < 32 hold heads rho, lanes >= 32 heads 4 + rho
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho) {
-            const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
-            const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;
-            const float f = lane < 32 ? flo : fhi;
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
-        }
+        rescale_heads(O, alpha, G, lane);
     }
     float ls = 0.f;
 #pragma unroll
@@ -1187,16 +1192,7 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
         const float m_safe = m_new > -INFINITY ? m_new : 0.f;
         const float alpha = fast_exp2(st.m - m_safe);
         if (__any(m_new > st.m && st.m > -INFINITY)) {
-#pragma unroll
-            for (int rho = 0; rho < 4; ++rho) {
-                const float flo = rho < G ? lane_bcast(alpha, rho) : 1.0f;
-                const float fhi = 4 + rho < G ? lane_bcast(alpha, 4 + rho) : 1.0f;
-                const float f = lane < 32 ? flo : fhi;
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) O[n][kk][rho] *= f;
-            }
+            rescale_heads(O, alpha, G, lane);
         }
         st.set(m_new, st.l * alpha, inv_c);
     }
@@ -1619,7 +1615,7 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 bool attn_mfma_shape_ok(const AttnParams &p) {
-    return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxG && p.rcap <= 4 * kNW * kResRows;
+    return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxGMfma && p.rcap <= 4 * kNW * kResRows;
 }
 
 bool attn_mfma_supported(const AttnParams &p) {

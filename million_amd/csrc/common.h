@@ -10,7 +10,8 @@ namespace million {
 typedef _Float16 f16;
 
 constexpr int kMaxSplits = 64;      // code splits per (b, hk); workspace is sized for this
-constexpr int kMaxG = 8;            // q heads per kv head handled by one workgroup
+constexpr int kMaxG = 8;            // q heads per kv head handled by one workgroup of the tile and scalar kernels
+constexpr int kMaxGMfma = 16;       // ... of the MFMA kernels (attn_mfma.hip): the 16 columns of the score tile
 constexpr int kCntBytes = 1024;     // granule of the counter / flag blocks at the start of the workspace
 // Workspace head: one 128-byte record per (b, kv head), then one int per batch item (second-level ticket), then
 // 2 x kFlagWords words per (b, kv head) (split flags, XCD census line), then the split partials.  Record words (u32):

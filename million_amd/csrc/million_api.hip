@@ -159,8 +159,9 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     memset(&p, 0, sizeof(p));
     p.bs = desc->bs; p.nh = desc->nh; p.nh_k = desc->nh_k; p.d = desc->d; p.M = desc->M; p.C = desc->C;
     if (p.bs <= 0 || p.nh <= 0 || p.nh_k <= 0 || p.nh % p.nh_k) { set_error("attn: bs=%d nh=%d nh_k=%d", p.bs, p.nh, p.nh_k); return MILLION_ERR_SHAPE; }
-    p.Gt = p.nh / p.nh_k;                     // any group size: more than kMaxG query heads per kv head run as several
-    p.G = p.Gt < kMaxG ? p.Gt : kMaxG;        // launches of up to kMaxG heads (attn_impl); G = heads of the (first) launch
+    p.Gt = p.nh / p.nh_k;                     // any group size: the MFMA kernels serve up to kMaxGMfma = 16 query heads per kv head
+    p.G = p.Gt < kMaxGMfma ? p.Gt : kMaxGMfma;      // in one launch, the tile / scalar kernels kMaxG = 8; bigger groups run as several
+                                              // launches (attn_impl).  G = heads of one launch, sized here for the largest
     p.g0 = 0;
     if (p.M <= 0 || p.d <= 0 || p.d % p.M || p.M % 4) { set_error("attn: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
     p.dm = p.d / p.M;
@@ -319,7 +320,7 @@ int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh
 
 size_t million_attn_workspace_bytes(const million_attn_desc *desc) {
     if (!desc || desc->nh_k <= 0 || desc->nh % desc->nh_k) return 0;
-    const int Gt = desc->nh / desc->nh_k, G = Gt < kMaxG ? Gt : kMaxG;
+    const int Gt = desc->nh / desc->nh_k, G = Gt < kMaxGMfma ? Gt : kMaxGMfma;
     size_t bytes = attn_partial_bytes(desc->bs, desc->nh_k, G, desc->d);
     // row-major V on the MFMA shapes: room for the transposed copy of the V codes (64-token pages)
     if (desc->v_layout == MILLION_KV_ROWMAJOR && desc->k_layout == MILLION_KV_ROWMAJOR && desc->n_tokens > 0 && desc->M > 0)
@@ -334,25 +335,55 @@ int million_workspace_init(void *workspace, size_t bytes, million_stream_t strea
     return MILLION_OK;
 }
 
+// p restricted to n query heads per kv head from g0 on (one launch of a bigger group)
+static AttnParams with_heads(const AttnParams &p, int g0, int n) {
+    AttnParams q = p;
+    q.g0 = g0;
+    q.G = n;
+    q.slot_floats = (int)slot_floats_for(n, p.d);
+    return q;
+}
+// the launches after the first of a call: a fused append has happened (the row is in the window; device-resident
+// lengths were advanced by the first launch)
+static void after_first_launch(AttnParams &p) {
+    if (p.k_new) {
+        p.k_new = p.v_new = nullptr;
+        if (!p.dev_lengths) p.r += 1;
+    }
+}
+
 int million_attn_kernel_kind(const million_attn_desc *desc) {
     AttnParams p;
     if (fill_attn_params(desc, p) != MILLION_OK) return -1;
     if (g_force_generic) return 0;
     if (attn_mfma_supported(p)) return 1;
     if (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) return 2;      // transpose + MFMA kernel
-    if (attn_tile_supported(p)) return 3;                                             // tile kernel
-    if (attn_tile_shape_ok(p) && !p.v_paged && !p.k_paged) return 4;                  // transpose + tile kernel
+    const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxG ? p.Gt : kMaxG);              // tile kernel: kMaxG heads per launch
+    if (attn_tile_supported(p8)) return 3;                                            // tile kernel
+    if (attn_tile_shape_ok(p8) && !p.v_paged && !p.k_paged) return 4;                 // transpose + tile kernel
     return 0;
 }
 
-// one query-head group (p.G <= kMaxG heads per kv head from p.g0 on): 1. the streaming / grouped MFMA kernels (d = 128,
-// M in {64, 32}); 2. the tile kernel (every other shape of the binding surface); 3. the scalar kernel
+// one query-head group (p.G heads per kv head from p.g0 on): 1. the streaming / grouped MFMA kernels (d = 128,
+// M in {64, 32}; up to kMaxGMfma heads); 2. the tile kernel (every other shape of the binding surface); 3. the scalar
+// kernel (both up to kMaxG heads: a bigger group the MFMA kernels hand back is split here)
 static int launch_group(const AttnParams &p, hipStream_t stream) {
     if (!g_force_generic) {
         if (attn_mfma_supported(p)) {
             const int rc_fast = launch_attn_mfma(p, stream);
             if (rc_fast != kAttnNotHandled) return rc_fast;
         }
+    }
+    if (p.G > kMaxG) {
+        for (int g1 = 0; g1 < p.G; g1 += kMaxG) {
+            AttnParams h = with_heads(p, p.g0 + g1, p.G - g1 < kMaxG ? p.G - g1 : kMaxG);
+            if (g1 > 0) after_first_launch(h);
+            const int rc_h = launch_group(h, stream);
+            if (rc_h != MILLION_OK) return rc_h;
+        }
+        return MILLION_OK;
+    }
+    if (!g_force_generic) {
         if (attn_tile_supported(p)) return launch_attn_tile(p, stream);
     }
     if (!g_force_generic) {
@@ -417,7 +448,8 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     // The fast kernels want V in transposed pages: the reference's 10-arg row-major layout is transposed into scratch
     // pages first (once per call, whatever the number of query-head groups below).
     AttnParams pl = p;
-    if (!g_force_generic && !p.v_paged && !p.k_paged && (attn_mfma_shape_ok(p) || attn_tile_shape_ok(p))) {
+    const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxG ? p.Gt : kMaxG);
+    if (!g_force_generic && !p.v_paged && !p.k_paged && (attn_mfma_shape_ok(p) || attn_tile_shape_ok(p8))) {
         pl.v_paged = 1; pl.v_identity = 1; pl.page_size = 64; pl.ps_shift = 6;
         pl.n_pages_cap = p.T > 0 ? (p.T + 63) / 64 : 1;
         if (p.T > 0) {
@@ -429,18 +461,14 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
             pl.v_codes = scratch;
         }
     }
-    // One launch serves up to kMaxG query heads per kv head; bigger groups (nh / nh_k = 16, ...) run as several launches
-    // on the same stream and workspace, each re-reading the codes.  A fused append happens in the first one: the later
-    // ones find the row in the window (r + 1 rows; device-resident lengths were advanced by the first launch).
-    for (int g0 = 0; g0 < p.Gt; g0 += kMaxG) {
-        AttnParams pg = pl;
-        pg.g0 = g0;
-        pg.G = p.Gt - g0 < kMaxG ? p.Gt - g0 : kMaxG;
-        pg.slot_floats = (int)slot_floats_for(pg.G, pg.d);
-        if (g0 > 0 && pg.k_new) {
-            pg.k_new = pg.v_new = nullptr;
-            if (!pg.dev_lengths) pg.r += 1;
-        }
+    // One launch of the MFMA kernels serves up to 16 query heads per kv head (the 16 columns of the score tile: Llama-3.1-405B's
+    // nh / nh_k = 16 reads its codes once), of the other kernels up to 8; bigger groups run as several launches on the same
+    // stream and workspace, each re-reading the codes.  A fused append happens in the first one: the later ones find the
+    // row in the window.
+    const int step = (!g_force_generic && attn_mfma_supported(pl)) ? kMaxGMfma : kMaxG;
+    for (int g0 = 0; g0 < p.Gt; g0 += step) {
+        AttnParams pg = with_heads(pl, g0, p.Gt - g0 < step ? p.Gt - g0 : step);
+        if (g0 > 0) after_first_launch(pg);
         const int rc_g = launch_group(pg, (hipStream_t)stream);
         if (rc_g != MILLION_OK) return rc_g;
     }

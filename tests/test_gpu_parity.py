@@ -250,6 +250,26 @@ def test_attn_peaked_softmax_forces_rescale(env, oracle):
     _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, "peaked paged")
 
 
+@pytest.mark.parametrize("G,heads", [(16, (13, 5)), (9, (8,)), (12, (11, 0))], ids=["G16", "G9", "G12"])
+def test_attn_peaked_softmax_rescale_above_eight_heads(G, heads, env, oracle):
+    """Groups of 9..16 query heads per kv head run in ONE launch of the MFMA kernels (second register row of the value
+    tile): a head of that second row (and one of the first) gets a key that matches it strongly late in the sequence, so
+    its softmax reference moves mid-stream and the rescale of rows 8..15 is exercised."""
+    torch, ops = env
+    nhk, T = 2, 3000
+    c = synth.attn_case(880 + G, 1, G * nhk, nhk, 128, 64, 256, T, 9)
+    kc = c["k_cents"].astype(np.float32)
+    for i, h in enumerate(heads):                      # code i of every subspace points along q of head h (kv head 0)
+        kc[:, i, :] = 3.0 * c["q"][0, h, 0].astype(np.float32).reshape(64, 2)
+    c["k_cents"] = kc.astype(np.float16)
+    for i, h in enumerate(heads):
+        c["k_codes"][0, 0, 2500 - 700 * i, :] = i
+        c["k_codes"][0, 0, 10 + i, :32] = i
+    gold = oracle.decode_attn(**c)
+    _check(_run_rowmajor(torch, ops, c, 64, 256), gold, f"peaked G={G} rowmajor")
+    _check(_run_paged(torch, ops, oracle, c, 64, 256, 64), gold, f"peaked G={G} paged")
+
+
 def test_bindings_module_dropin(env, oracle):
     """The reference's call sequence (pq_utils.py:61-94; test_kernel.py:45-69) through `bindings`."""
     torch, ops = env
@@ -1440,8 +1460,9 @@ def test_two_streams_concurrent_calls(env, oracle):
 @pytest.mark.parametrize("G", [12, 16, 32])
 @pytest.mark.parametrize("d,M", [(128, 64), (128, 32), (64, 32), (128, 16)], ids=["stream64", "stream32", "tile-d64", "tile-m16"])
 def test_attn_query_groups_above_eight(G, d, M, env, oracle):
-    """nh / nh_k > 8 (e.g. 128 query heads over 8 kv heads): served as several launches of up to 8 heads per kv head; the
-    reference takes any group size (one kernel block per query head, Kernel.cuh:44-52)."""
+    """nh / nh_k > 8 (e.g. 128 query heads over 8 kv heads): the MFMA kernels serve up to 16 heads per kv head in one launch
+    (32: two), the tile and scalar kernels up to 8 per launch; the reference takes any group size (one kernel block per
+    query head, Kernel.cuh:44-52)."""
     torch, ops = env
     nhk, T, r, C = 2, 1500, 40, 256
     c = synth.attn_case(9200 + G + d + M, 2, G * nhk, nhk, d, M, C, T, r, Lt=128)
@@ -1455,12 +1476,13 @@ def test_attn_query_groups_above_eight(G, d, M, env, oracle):
         ops.set_force_generic(False)
 
 
+@pytest.mark.parametrize("G", [16, 24], ids=["one-launch", "two-launches"])
 @pytest.mark.parametrize("use_dl", [False, True], ids=["host-lengths", "device-lengths"])
-def test_fused_append_with_sixteen_heads_per_kv_head(use_dl, env, oracle):
-    """Fused append with two launches per call (G = 16): the row is appended once, both head groups attend to it, and
-    device-resident r advances by exactly one per call."""
+def test_fused_append_with_sixteen_heads_per_kv_head(use_dl, G, env, oracle):
+    """Fused append with G = 16 (one launch on the MFMA kernels since round 3) and G = 24 (launches of 16 + 8 heads): the
+    row is appended once, every head attends to it, and device-resident r advances by exactly one per call."""
     torch, ops = env
-    bs, nhk, G, d, M, C, T, r0, ps = 2, 2, 16, 128, 64, 256, 700, 37, 64
+    bs, nhk, d, M, C, T, r0, ps = 2, 2, 128, 64, 256, 700, 37, 64
     c = synth.attn_case(9300, bs, G * nhk, nhk, d, M, C, T, r0, Lt=128)
     t = _dev(torch, c)
     kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
@@ -1482,7 +1504,7 @@ def test_fused_append_with_sixteen_heads_per_kv_head(use_dl, env, oracle):
         torch.cuda.synchronize()
         k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
         r += 1
-        _check(out.cpu().numpy(), oracle.decode_attn(**dict(c, k_res=k_hist, v_res=v_hist, r=r)), f"G=16 fused append step {step}")
+        _check(out.cpu().numpy(), oracle.decode_attn(**dict(c, k_res=k_hist, v_res=v_hist, r=r)), f"G={G} fused append step {step}")
     np.testing.assert_array_equal(kr.cpu().numpy()[:, :, r0:r], k_hist[:, :, r0:r])
     if use_dl:
         assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
