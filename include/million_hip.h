@@ -145,7 +145,8 @@ enum {
 
 typedef struct {
     uint32_t struct_size;         /* = sizeof(million_attn_desc) */
-    int32_t bs, nh, nh_k;         /* any nh / nh_k >= 1: more than 8 query heads per kv head run as several launches inside the call */
+    int32_t bs, nh, nh_k;         /* any nh / nh_k >= 1: up to 16 query heads per kv head are one launch on the d = 128, M in {64, 32}
+                                     shapes (8 on the others); bigger groups run as several launches inside the call */
     int32_t d, M, C;
     int32_t n_tokens;             /* T: quantised tokens per (b, hk); upper bound if dev_lengths != NULL */
     int32_t r;                    /* valid residual rows, 0 <= r <= resid_cap */
@@ -165,6 +166,10 @@ typedef struct {
                                      lengths are read on the device (graph replay with changing lengths); every
                                      batch item has its own row, so requests of different lengths can share a
                                      launch - n_tokens above is then only the bound the grid is sized for */
+    int32_t k_pool_pages;         /* PAGED: pages in the K / V pools handed to the call; 0 = not given.  Page ids are trusted, */
+    int32_t v_pool_pages;         /* as in the reference (paged_pq_utils.py:440-441): only a library built with
+                                     -DMILLION_DEBUG_CHECK_IDS (make debug-ids -> libmillion_hip_dbgids.so) reads these,
+                                     maps ids outside [0, pool_pages) to page 0 and counts them (million_debug_bad_page_ids) */
 } million_attn_desc;
 
 size_t million_attn_workspace_bytes(const million_attn_desc *desc);
@@ -256,6 +261,10 @@ int million_residual_append(const void *k_new, const void *v_new, void *k_resid,
  * lengths: n_tokens += n_flushed, r -= n_flushed, resid_start = (resid_start + n_flushed) % resid_cap. */
 int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int resid_cap, million_stream_t stream);
 
+/* Diagnostics only.  -1 in the product build.  In a library built with -DMILLION_DEBUG_CHECK_IDS: waits for the device and
+ * returns (and clears) the number of page ids outside [0, k_pool_pages) / [0, v_pool_pages) that the three decode-attention
+ * kernels have met since the last call; such ids were read as page 0 instead of as out-of-bounds addresses. */
+int million_debug_bad_page_ids(void);
 /* Diagnostics only: when `buf` is non-NULL the decode-attention kernels store up to 16 x uint64 realtime-counter
  * stamps (100 MHz) per wave at their phase boundaries into buf (grid_size * 8 waves * 32 slots entries).  NULL = off. */
 void million_debug_set_stamp_buffer(void *buf);

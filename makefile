@@ -5,6 +5,9 @@ PYTHON ?= python3
 bindings:
 	$(PYTHON) -m million_amd.build
 
+debug-ids:         # diagnostic variant: page ids bounds-checked in the decode-attention kernels (MILLION_HIP_LIB=million_amd/libmillion_hip_dbgids.so)
+	$(PYTHON) -m million_amd.build --debug-ids
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -21,6 +24,6 @@ bench:
 	$(PYTHON) bench.py
 
 clean:
-	rm -f million_amd/libmillion_hip.so oracle/libpq_oracle.so
+	rm -f million_amd/libmillion_hip.so million_amd/libmillion_hip_dbgids.so oracle/libpq_oracle.so
 
-.PHONY: bindings oracle golden test test-gpu bench clean
+.PHONY: bindings debug-ids oracle golden test test-gpu bench clean

@@ -35,7 +35,7 @@ class AttnDesc(ctypes.Structure):
                 ("k_layout", c_i32), ("v_layout", c_i32), ("page_size", c_i32), ("n_pages_cap", c_i32),
                 ("page_ids_i64", c_i32), ("v_pages_dense", c_i32),
                 ("k_stride_b", c_i64), ("k_stride_h", c_i64), ("v_stride_b", c_i64), ("v_stride_h", c_i64),
-                ("dev_lengths", c_vp)]
+                ("dev_lengths", c_vp), ("k_pool_pages", c_i32), ("v_pool_pages", c_i32)]
 
 
 class PrefillDesc(ctypes.Structure):
@@ -67,6 +67,7 @@ SYMBOLS = {
     "million_prefill_attn": (c_i32, [ctypes.POINTER(PrefillDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "million_set_force_generic": (None, [c_i32]),
     "million_debug_set_stamp_buffer": (None, [c_vp]),
+    "million_debug_bad_page_ids": (c_i32, []),
     "million_debug_rows_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "million_lengths_advance": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "million_residual_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64,

@@ -14,6 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmillion_hip.so"
+LIB_DEBUG_IDS = HERE / "libmillion_hip_dbgids.so"      # same sources with -DMILLION_DEBUG_CHECK_IDS (page ids bounds-checked)
 SOURCES = ["million_api.hip", "encode.hip", "attn_generic.hip", "attn_tile.hip", "attn_mfma.hip", "prefill.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value"]
 
@@ -25,25 +26,28 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libmillion_hip.so)")
 
 
-def needs_build() -> bool:
-    if not LIB.exists():
+def needs_build(lib: Path = LIB) -> bool:
+    if not lib.exists():
         return True
-    t = LIB.stat().st_mtime
+    t = lib.stat().st_mtime
     deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "million_hip.h"]
     return any(p.stat().st_mtime > t for p in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every source to an object in parallel (the attention kernels dominate: ~25 s), then link."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, debug_ids: bool = False) -> Path:
+    """Compile every source to an object in parallel (the attention kernels dominate: ~25 s), then link.
+    debug_ids: the diagnostic variant libmillion_hip_dbgids.so (load it with MILLION_HIP_LIB=...): the three decode-attention
+    kernels map page ids outside the pools to page 0 and count them (million_debug_bad_page_ids)."""
+    LIB = LIB_DEBUG_IDS if debug_ids else globals()["LIB"]
+    if not force and not needs_build(LIB):
         return LIB
     save_temps = bool(os.environ.get("MILLION_SAVE_TEMPS"))
-    objdir = HERE.parent / "build" / "obj"
+    objdir = HERE.parent / "build" / ("obj_dbgids" if debug_ids else "obj")
     # ISA / IR dumps go to scratch (gpurun_out/ never ships to the GPU box)
     cwd = HERE.parent / "gpurun_out" / "save_temps" if save_temps else objdir
     objdir.mkdir(parents=True, exist_ok=True)
     cwd.mkdir(parents=True, exist_ok=True)
-    cflags = [f for f in FLAGS if f != "-shared"]
+    cflags = [f for f in FLAGS if f != "-shared"] + (["-DMILLION_DEBUG_CHECK_IDS=1"] if debug_ids else [])
     cmds = []
     for src in SOURCES:
         cmd = [hipcc(), *cflags, "-c", "-o", str(objdir / (src + ".o")), str(CSRC / src)]
@@ -63,16 +67,16 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         elif verbose and out:
             sys.stderr.write(out)
     if failed:
-        raise RuntimeError("hipcc failed building libmillion_hip.so")
+        raise RuntimeError(f"hipcc failed building {LIB.name}")
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *[str(objdir / (src + ".o")) for src in SOURCES]]
     if verbose:
         print(" ".join(link), flush=True)
     r = subprocess.run(link, cwd=str(objdir), capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed linking libmillion_hip.so")
+        raise RuntimeError(f"hipcc failed linking {LIB.name}")
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug_ids="--debug-ids" in sys.argv))

@@ -184,6 +184,13 @@ __device__ __forceinline__ void load_pids4(const AttnParams &p, int bh, const in
             o[0].k = v0; o[1].k = v1; o[2].k = v2; o[3].k = v3;
         }
     }
+#ifdef MILLION_DEBUG_CHECK_IDS
+#pragma unroll
+    for (int k = 0; k < kRing; ++k) {
+        if (p.k_paged) o[k].k = MILLION_CHECK_KID(p, o[k].k);
+        if (!p.v_identity) o[k].v = MILLION_CHECK_VID(p, o[k].v);
+    }
+#endif
 }
 
 // Request the 16-byte loads of one 32-token unit (see UnitCodes): two for the K bytes, two for the V bytes.
@@ -1321,6 +1328,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         if (k_paged) vpk = ids64 ? (int)p.k_ids64[idx] : p.k_ids32[idx];
         if (v_ident) vpv = (int)idx;
         else vpv = ids64 ? (int)p.v_ids64[idx] : p.v_ids32[idx];
+#ifdef MILLION_DEBUG_CHECK_IDS
+        {      // lane = round: entries of pages beyond the context (host bound) are preloaded but never used
+            const bool live = pg0 + lane * pg_step < p.n_pages_cap && ((long long)(pg0 + lane * pg_step) << p.ps_shift) < p.T;
+            if (k_paged) vpk = MILLION_CHECK_KID(p, ids64 ? (long long)p.k_ids64[idx] : (long long)vpk, live);
+            if (!v_ident) vpv = MILLION_CHECK_VID(p, ids64 ? (long long)p.v_ids64[idx] : (long long)vpv, live);
+        }
+#endif
     }
     v8f16 qb[4];
     {

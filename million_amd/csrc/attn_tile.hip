@@ -202,6 +202,10 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
             o.k = kid_base[idx * kid_stride];                               // 32-bit index arithmetic: a 64-bit multiply
             const int v = vid_base[idx * vid_stride];                       // here made hipcc tie a wait to an in-flight load
             o.v = p.v_identity ? idx : v;
+#ifdef MILLION_DEBUG_CHECK_IDS
+            if (p.k_paged) o.k = MILLION_CHECK_KID(p, o.k);
+            if (!p.v_identity) o.v = MILLION_CHECK_VID(p, o.v);
+#endif
             return o;
         };
         auto load_codes = [&](int t0, Pids id) -> Codes {

@@ -61,7 +61,29 @@ struct AttnParams {
     int slot_floats; // floats per partial slot = G*d + 2*G, padded to whole 128-byte lines (no line is shared by two slots)
     float scale_log2e;
     unsigned long long *dbg;   // diagnostic stamp buffer (million_debug_set_stamp_buffer), normally null
+    int k_pool_pages, v_pool_pages;   // pages in the pools (0 = not given): read only under MILLION_DEBUG_CHECK_IDS
+    int *bad_ids;                     // MILLION_DEBUG_CHECK_IDS: device counter of out-of-range page ids, else null
 };
+
+// Page ids are trusted in the product build, as in the reference.  A library built with -DMILLION_DEBUG_CHECK_IDS routes
+// every id the three attention kernels read through checked_page_id: an id outside the pool becomes page 0 (a valid
+// address) and is counted.  `live`: the id is really used (the streaming kernel preloads table entries beyond the
+// context, which may hold anything); dead ids are clamped without being counted.
+#ifdef MILLION_DEBUG_CHECK_IDS
+template <class T>
+__device__ __forceinline__ T checked_page_id(const AttnParams &p, T id, int pool, bool live = true) {
+    if (pool > 0 && (unsigned long long)(long long)id >= (unsigned long long)pool) {
+        if (live && p.bad_ids) atomicAdd(p.bad_ids, 1);
+        return (T)0;
+    }
+    return id;
+}
+#define MILLION_CHECK_KID(p, id, ...) ::million::checked_page_id((p), (id), (p).k_pool_pages, ##__VA_ARGS__)
+#define MILLION_CHECK_VID(p, id, ...) ::million::checked_page_id((p), (id), (p).v_pool_pages, ##__VA_ARGS__)
+#else
+#define MILLION_CHECK_KID(p, id, ...) (id)
+#define MILLION_CHECK_VID(p, id, ...) (id)
+#endif
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -134,12 +156,12 @@ __device__ __forceinline__ void load_lengths(const AttnParams &p, int b, int &T,
 
 __device__ __forceinline__ long long k_page_id(const AttnParams &p, int bh, int page) {
     const long long idx = (long long)bh * p.n_pages_cap + page;
-    return p.ids64 ? p.k_ids64[idx] : (long long)p.k_ids32[idx];
+    return MILLION_CHECK_KID(p, p.ids64 ? p.k_ids64[idx] : (long long)p.k_ids32[idx]);
 }
 __device__ __forceinline__ long long v_page_id(const AttnParams &p, int bh, int page) {
     const long long idx = (long long)bh * p.n_pages_cap + page;
     if (p.v_identity) return idx;
-    return p.ids64 ? p.v_ids64[idx] : (long long)p.v_ids32[idx];
+    return MILLION_CHECK_VID(p, p.ids64 ? p.v_ids64[idx] : (long long)p.v_ids32[idx]);
 }
 
 // Diagnostic stamps (off unless a buffer is set): lane 0 of each of the first 8 waves of a workgroup stores the

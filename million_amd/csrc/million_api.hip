@@ -224,6 +224,29 @@ void million_set_force_generic(int on) {
     million::set_mfma_policy(on == 2 ? 1 : 0);
 }
 void million_debug_set_stamp_buffer(void *buf) { g_dbg = (unsigned long long *)buf; }
+
+#ifdef MILLION_DEBUG_CHECK_IDS
+// device counter of out-of-range page ids (one per process; a diagnostic build is not for concurrent devices)
+static int *g_bad_ids = nullptr;
+static int *bad_ids_counter() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (hipMalloc((void **)&g_bad_ids, sizeof(int)) != hipSuccess) { g_bad_ids = nullptr; return; }
+        (void)hipMemset(g_bad_ids, 0, sizeof(int));
+    });
+    return g_bad_ids;
+}
+int million_debug_bad_page_ids(void) {
+    int *c = bad_ids_counter();
+    if (!c) return -1;
+    int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, c, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemset(c, 0, sizeof(int));
+    return n;
+}
+#else
+int million_debug_bad_page_ids(void) { return -1; }
+#endif
 int million_debug_rows_reduce(const float *in64, float *out_max64, float *out_sum64, million_stream_t stream) {
     return launch_rows_reduce_check(in64, out_max64, out_sum64, (hipStream_t)stream);
 }
@@ -444,6 +467,10 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     p.ws_cnt2 = (int *)((unsigned *)workspace + head_pairs(p.bs, p.nh_k) * kRecWords);
     p.ws_flags = (unsigned *)((char *)workspace + attn_cnt_bytes(p.bs, p.nh_k));
     p.dbg = g_dbg;
+    p.k_pool_pages = desc->k_pool_pages; p.v_pool_pages = desc->v_pool_pages;
+#ifdef MILLION_DEBUG_CHECK_IDS
+    p.bad_ids = bad_ids_counter();
+#endif
     p.ws_part = (float *)((char *)workspace + attn_cnt_bytes(p.bs, p.nh_k) + attn_flag_bytes(p.bs, p.nh_k));
     // The fast kernels want V in transposed pages: the reference's 10-arg row-major layout is transposed into scratch
     // pages first (once per call, whatever the number of query-head groups below).

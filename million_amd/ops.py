@@ -267,6 +267,11 @@ def make_attn_desc(q, k_res, *, nh_k, M, C, n_tokens, r, resid_start=0, k_paged=
     if not v_paged and v_codes is not None:
         desc.v_stride_b, desc.v_stride_h = v_codes.stride(0), v_codes.stride(1)
     desc.dev_lengths = _ptr(dev_lengths)
+    # pool sizes: read only by the MILLION_DEBUG_CHECK_IDS build of the library (page ids are trusted otherwise)
+    if k_paged and k_codes is not None:
+        desc.k_pool_pages = k_codes.shape[0]
+    if v_paged and not v_pages_dense and v_codes is not None:
+        desc.v_pool_pages = v_codes.shape[0]
     return desc
 
 
@@ -438,7 +443,7 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
     paged = v_page_ids is not None
     stream = _stream()      # part of the signature: the workspace of a plan belongs to one (device, stream)
     sig = (stream, query.shape, query.dtype, query.is_contiguous(), key_codes.shape[1], key_codes.stride(), key_codes.dtype,
-           value_codes.shape[1:] if paged else value_codes.stride(), value_codes.dtype,
+           value_codes.shape if paged else value_codes.stride(), value_codes.dtype,
            key_residuals.shape, key_residuals.stride(), key_residuals.dtype, value_residuals.shape, value_residuals.stride(),
            value_residuals.dtype,
            (v_page_ids.shape, v_page_ids.dtype, v_page_ids.is_contiguous(), page_size) if paged else None,
@@ -459,7 +464,7 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
             if paged:
                 plan.desc = make_attn_desc(query, key_residuals, nh_k=key_residuals.shape[1], M=M, C=C, n_tokens=T, r=int(r),
                                            k_paged=False, v_paged=True, page_size=int(page_size), n_pages_cap=v_page_ids.shape[2],
-                                           page_ids_i64=v_page_ids.dtype == torch.int64, k_codes=key_codes)
+                                           page_ids_i64=v_page_ids.dtype == torch.int64, k_codes=key_codes, v_codes=value_codes)
             else:
                 plan.desc = make_attn_desc(query, key_residuals, nh_k=key_residuals.shape[1], M=M, C=C, n_tokens=T, r=int(r),
                                            k_paged=False, v_paged=True, page_size=64, n_pages_cap=(T + 63) // 64,

@@ -1510,6 +1510,32 @@ def test_fused_append_with_sixteen_heads_per_kv_head(use_dl, G, env, oracle):
         assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
 
 
+def test_debug_build_bounds_checks_page_ids(env):
+    """`make debug-ids` (-DMILLION_DEBUG_CHECK_IDS): the three decode-attention kernels map page ids outside the pools to
+    page 0 and count them; the product library trusts page ids like the reference (paged_pq_utils.py:440-441) and answers
+    -1.  The diagnostic library is loaded by a child process (one library per process: million_amd/_lib.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from million_amd import _lib
+    assert _lib.load().million_debug_bad_page_ids() == -1            # product build: no check compiled in
+    root = Path(__file__).resolve().parents[1]
+    dbg = root / "million_amd" / "libmillion_hip_dbgids.so"
+    if not dbg.exists():
+        pytest.skip("million_amd/libmillion_hip_dbgids.so not built (make debug-ids)")
+    env_ = dict(os.environ, MILLION_HIP_LIB=str(dbg))
+    r = subprocess.run([sys.executable, str(root / "tests" / "dbgids_child.py")], env=env_, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["lib"] == dbg.name
+    assert [c["name"] for c in res["cases"]] == ["stream", "stream-i64", "tile", "scalar"]
+    for c in res["cases"]:
+        assert c["clean_bad_ids"] == 0 and c["clean_err"] < 1e-3, c
+        assert c["bad_ids"] >= 3 and c["finite"] and c["other_head_err"] < 1e-3 and c["hurt_head_moved"], c
+
+
 # ---------------------------------------------------------------- prompt (prefill) attention on fp16 K/V -------------------
 def _sdpa_ref_rows(q, k, v, rows, q_pos0=0, causal=True):
     """fp64 reference of selected query rows: q (bs, nh, n_q, d), k / v (bs, nh_k, n_kv, d) numpy -> (bs, nh, len(rows), d)."""
