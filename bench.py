@@ -70,7 +70,12 @@ def parse(argv=None):
     ap.add_argument("--force-generic", action="store_true", help="A/B: use the generic LUT kernel")
     ap.add_argument("--kernel-policy", type=int, default=0, help="A/B knob passed to million_set_force_generic")
     ap.add_argument("--roofline-launches", type=int, default=256)
-    ap.add_argument("--inline-flush", action="store_true", help="A/B: flush each layer's window in front of its attention launch instead of ahead on a side stream")
+    ap.add_argument("--flush-mode", default="encode-ahead", choices=["encode-ahead", "ahead", "inline"],
+                    help="encode-ahead: the oldest window page is encoded (all layers, one launch on a side stream) in an earlier step and the "
+                         "flush step only commits; ahead (round 3, A/B): the flush launches of the flush step on a side stream; inline (A/B): in front of each layer's attention")
+    ap.add_argument("--flush-depth", type=int, default=2, help="layers the side-stream flush launches run ahead of the attention that needs them (A/B; 99 = all at the start of the step)")
+    ap.add_argument("--ea-steps", type=int, default=0, help="A/B: decode steps the encode-ahead of all layers is spread over (0: the cache's choice)")
+    ap.add_argument("--ea-launches", type=int, default=0, help="A/B: launches the encode-ahead of all layers is split into (0: the cache's choice)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end TPOT / TTFT record (N = 1 only; ~1-2 min)")
     ap.add_argument("--e2e-cap-s", type=float, default=240.0, help="no end-to-end backend is started later than this many seconds into the e2e leg")
     ap.add_argument("--dry-cpu", action="store_true",
@@ -176,9 +181,14 @@ def main():
     vn = [torch.randn(bs, nhk, 1, d, device=dev).half() for _ in range(layers)]
     outs = [torch.empty(bs, nh, 1, d, device=dev, dtype=torch.float16) for _ in range(layers)]
 
+    cache.encode_ahead_launches = args.ea_launches or None
+    cache.encode_ahead_steps = args.ea_steps or None
+
     def step_eager(use_dl):
-        if not args.inline_flush and cache.next_step_flushes():
-            cache.flush_ahead(use_dev_lengths=use_dl)      # all layers' flushes on a side stream, joined layer by layer
+        if args.flush_mode == "encode-ahead":
+            cache.begin_step(use_dev_lengths=use_dl)      # oldest window page encoded ahead of its flush step / committed
+        elif args.flush_mode == "ahead" and cache.next_step_flushes():
+            cache.flush_ahead(use_dev_lengths=use_dl, depth=args.flush_depth)      # flushes on a side stream, joined layer by layer
         for l in range(layers):
             cache.decoding_with_pages(q[l], kn[l], vn[l], l, out=outs[l], use_dev_lengths=use_dl)
 
@@ -189,8 +199,10 @@ def main():
         dl_backup = [t.clone() for t in cache.lengths]
         step_eager(True)                       # eager once: allocates the workspace, warms caches
         torch.cuda.synchronize()
-        for name, r_cap in (("plain", min(r0, cap - 1)), ("flush", cap)):
-            cache.set_host_state((st[0], [r_cap] * layers, st[2], st[3]))
+        for name, state in cache.capture_states(st):
+            if args.flush_mode != "encode-ahead" and (name.startswith("pre") or name == "commit"):
+                continue
+            cache.set_host_state(state)
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 step_eager(True)
@@ -200,12 +212,18 @@ def main():
             t.copy_(b)
         torch.cuda.synchronize()
 
+    def step_kind():
+        if args.flush_mode == "encode-ahead":
+            return cache.next_step_kind()
+        return "flush" if cache.next_step_flushes() else "plain"
+
     def one_step():
         if args.no_graph:
             step_eager(False)
         else:
-            graphs["flush" if cache.next_step_flushes() else "plain"].replay()
-            cache.note_replayed_step()
+            kind = step_kind()
+            graphs[kind].replay()
+            cache.note_replayed_step(kind)
 
     for _ in range(PRE + args.warmup):
         one_step()
@@ -224,10 +242,11 @@ def main():
     elapsed64 = sharding.timed_steps(counted_step, 64, torch.cuda.synchronize, dist if world > 1 else None)
     value64, ms64 = sharding.aggregate_throughput(bs, 64, elapsed64, world)
     # and the two kinds of step apart (HIP events around every step of another period): what a flush step costs
-    step_ev, step_is_flush = [], []
+    step_ev, step_is_flush, step_kinds = [], [], []
     for _ in range(64):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         step_is_flush.append(cache.next_step_flushes())
+        step_kinds.append(step_kind())
         a.record()
         one_step()
         b.record()
@@ -238,6 +257,11 @@ def main():
     flush_ms = [t for t, f in zip(step_ms, step_is_flush) if f]
     plain_step_ms = sorted(plain_ms)[len(plain_ms) // 2] if plain_ms else None
     flush_step_ms = sum(flush_ms) / len(flush_ms) if flush_ms else None
+    pre_ms = [t for t, k in zip(step_ms, step_kinds) if k.startswith("pre")]
+    pre_step_ms = sum(pre_ms) / len(pre_ms) if pre_ms else None
+    plain_only = [t for t, k in zip(step_ms, step_kinds) if k == "plain"]
+    if plain_only:
+        plain_step_ms = sorted(plain_only)[len(plain_only) // 2]
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream ----
     # `achieved` uses the average launch duration over a region of nl back-to-back launches between ONE pair of events
@@ -311,12 +335,19 @@ def main():
                                              f"per-GPU batch {bs} (BASELINE configs[3] = 16 requests over 8 GPUs): the like-for-like "
                                              f"1-GPU base is `bench.py --gpus 1 --batch-per-gpu {bs}`, not the default configs[2] line"),
                        "flush_steps_in_timed_region": flushes_timed,
-                       "flush": "in-line" if args.inline_flush else "ahead: all layers' flush launches on a side stream, each layer's attention waits for its own",
+                       "flush": {"encode-ahead": "encode-ahead: the oldest window page of ALL layers is encoded by one launch on a side stream "
+                                                 f"when the window holds {cache.encode_ahead_at()} rows (beside that step's attention launches); the flush "
+                                                 "step only moves the lengths (one launch for all layers)",
+                                 "ahead": f"ahead: flush launches of the flush step on a side stream, issued {args.flush_depth} layers ahead; each layer's attention waits for its own",
+                                 "inline": "in-line"}[args.flush_mode],
                        "steady_state_64_steps": {"value": round(value64, 2), "ms_per_step": round(ms64, 4),
-                                                 "note": "one whole flush period (63 plain steps + 1 flush step)"},
+                                                 "note": "one whole flush period (64 steps: plain steps, one encode-ahead step, one flush / commit step)"},
                        "plain_step_ms": round(plain_step_ms, 4) if plain_step_ms else None,
                        "flush_step_ms": round(flush_step_ms, 4) if flush_step_ms else None,
                        "flush_step_over_plain_step": round(flush_step_ms / plain_step_ms, 3) if plain_step_ms and flush_step_ms else None,
+                       "encode_ahead_steps_per_period": len(pre_ms),
+                       "encode_ahead_step_ms": round(pre_step_ms, 4) if pre_step_ms else None,
+                       "encode_ahead_step_over_plain_step": round(pre_step_ms / plain_step_ms, 3) if plain_step_ms and pre_step_ms else None,
                        "launch": "eager" if args.no_graph else "hipGraph replay",
                        "kernel": "generic-LUT" if args.force_generic else ("auto" if not args.kernel_policy else f"policy{args.kernel_policy}")},
             "roofline": {"bound": "hbm", "kernel": "fused decode attention (one launch per layer-call)",

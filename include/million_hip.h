@@ -113,6 +113,22 @@ int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const 
                      const void *k_cents, const void *v_cents, void *k_pool, void *v_pool,
                      const int32_t *page_ids, int32_t *dev_lengths, int resid_cap, int min_r, million_stream_t stream);
 
+/* The same for n_layers layers of a cache in ONE launch, and optionally WITHOUT moving the window (encode-ahead).
+ * The layers' K / V window buffers, page tables and length rows lie rows_layer_stride fp16 elements, ids_layer_stride
+ * int32 and lengths_layer_stride int32 apart (layer 0 at the pointers given); pools and codebooks are shared, as in the
+ * reference (one PagedPQCache, one codebook pair for all layers: paged_pq_utils.py:70-80, pq_utils.py:149-159).
+ * advance = 0: the rows are encoded into the pages of tokens [n_tokens, n_tokens + n) and nothing else changes - the oldest
+ * page of window rows is complete long before the window is full (the reference flushes at r >= extended_residual_size,
+ * paged_pq_utils.py:359-361; the rows exist from r >= page_size on), so a cache can encode them during any earlier step,
+ * beside that step's attention launches (the kernel runs 4 waves of <= 32 registers per workgroup: it fits on a CU next to
+ * an attention workgroup), and commit the flush later with million_lengths_advance alone.  Codes and final state are
+ * identical to million_pq_flush at the flush step.  min_r (device lengths) then means "rows present": pass page_size. */
+int million_pq_flush_layers(const million_encode_desc *desc, const void *k_rows, const void *v_rows,
+                            const void *k_cents, const void *v_cents, void *k_pool, void *v_pool,
+                            const int32_t *page_ids, int32_t *dev_lengths, int resid_cap, int min_r,
+                            int n_layers, int64_t rows_layer_stride, int64_t ids_layer_stride, int64_t lengths_layer_stride,
+                            int advance, million_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PQ decode (reconstruction).
  * Replaces: sa_decode_4d (scripts/utils/pq_utils.py:501-540): out[row, m*d_m + k] = cents[m, codes[row, m], k].

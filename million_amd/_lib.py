@@ -56,6 +56,8 @@ SYMBOLS = {
     "million_pq_encode": (c_i32, [ctypes.POINTER(EncodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "million_pq_decode": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "million_pq_flush": (c_i32, [ctypes.POINTER(EncodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "million_pq_flush_layers": (c_i32, [ctypes.POINTER(EncodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                        c_i32, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "million_transpose_v_codes": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "million_attn_workspace_bytes": (c_sz, [ctypes.POINTER(AttnDesc)]),
     "million_workspace_init": (c_i32, [c_vp, c_sz, c_vp]),

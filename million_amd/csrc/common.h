@@ -399,7 +399,8 @@ bool attn_tile_supported(const AttnParams &p);   // shape taken by the tile kern
 bool attn_tile_shape_ok(const AttnParams &p);    // shape taken by the tile kernel once V is transposed
 int launch_encode(const EncParams &p, hipStream_t s);
 int launch_decode(const void *codes, const f16 *cents, f16 *out, long long n_rows, int M, int C, int dm, hipStream_t s);
-int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, int min_r, hipStream_t s);
+struct FlushLayers { int n_layers; long long x_ls, ids_ls, len_ls; int advance; };      // one layer: {1, 0, 0, 0, 1}
+int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, int min_r, const FlushLayers &ly, hipStream_t s);
 bool attn_mfma_shape_ok(const AttnParams &p);
 int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hipStream_t s);
 bool attn_mfma_supported(const AttnParams &p);

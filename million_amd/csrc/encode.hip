@@ -206,32 +206,46 @@ __global__ __launch_bounds__(kEncBlock) void pq_encode_small_kernel(EncParams p)
 // ---- one launch per flush (reference flush_to_pages, paged_pq_utils.py:130-210: encode the oldest page of K rows, of
 // V rows, then move the window).
 //
-// Round-3 form.  The round-2 kernel ran one 256-thread workgroup per (head, side, subspace): 1024 workgroups whose
-// lengths ticket was 1024 same-address atomics (~11 ns each at the memory side: ~11 us of fan-in) behind FIVE dependent
-// cold round trips (codebook row -> lengths -> window rows -> page id -> ticket): 18.8 us per launch inside a decode step
-// (rocprofv3, profiles/r02_kernel_stats.csv), 7.5 us only when replayed back to back with warm caches.  Now:
-//   * a workgroup = (64-token block, side, subspace, group of HP kv heads), 16 waves: wave = (head, part of the
-//     centroid range); the subspace's codebook row is fetched once per workgroup, not once per head;
-//   * everything that does not depend on the lengths is requested first; the window rows and the page id follow the
-//     lengths in ONE round trip;
+// History.  Round 2: one 256-thread workgroup per (head, side, subspace), 1024 workgroups, a 1024-arrival lengths ticket
+// behind five dependent cold round trips: 18.8 us per launch inside a decode step.  Round 3, first form: 16-wave
+// workgroups (wave = head x centroid part), everything independent of the lengths requested first, early ticket: 9.5 us
+// in situ - but a 16-wave workgroup needs a CU to itself, and a decode step has none to spare: every attention launch puts
+// one 138-KiB workgroup on each CU, so each flush launch on the side stream (PagedPQCache.flush_ahead) held some
+// attention workgroups back for its own duration (flush step = 1.21 x a plain step).
+// Now the flush is built to run BESIDE the attention workgroups instead of between them: 4 waves (one per SIMD),
+// <= 32 VGPRs, 5 KiB of LDS.  An attention workgroup holds 2 x 240 of a SIMD's 512 registers and 138 of the CU's 160 KiB,
+// so one flush workgroup fits on every CU while attention runs, and a new attention workgroup fits while a flush
+// workgroup is resident: neither waits for the other; the flush's ~2300 vector instructions per wave fill issue slots
+// the latency-bound front and tail of the attention kernel leave empty.
+//   * a workgroup = (64-token block, side, subspace, group of hp <= 4 kv heads): wave = (head, part of the centroid
+//     range; parts = 4 / hp, 1 at nh_k >= 4); the subspace's codebook row is fetched once per workgroup;
+//   * no load sits in a conditional (clamped indices instead: hipcc answers a conditional load with vmcnt(0)): the
+//     codebook row goes out first, the lengths come through the scalar cache meanwhile, the window row and the page id
+//     follow the lengths in ONE round trip;
 //   * the ticket (4th word of the batch item's device lengths) is taken as soon as every wave of the workgroup HAS READ
 //     the lengths - all it protects - so its fan-in (<= 256 arrivals) overlaps the centroid scan; the workgroup whose
 //     ticket was last advances the lengths at its end.
 // Codes are bit-identical to pq_encode_kernel / the oracle: same IEEE operations in the same order per (row, centroid),
 // strict '<' over increasing c within a part, parts combined in centroid order.
-constexpr int kFlushWaves = 16;
+constexpr int kFlushWaves = 4;
 struct FlushParams {
     EncParams k, v;
     int *dev_lengths_w;      // writable alias of k.dev_lengths (null: host lengths, nothing to advance)
     int n_flush, rcap;
     int min_r;               // device lengths only: batch items whose window holds fewer rows are skipped (0: flush every item)
-    int hp;                  // kv heads per workgroup (1..16)
+    int hp;                  // kv heads per workgroup (1, 2 or 4)
     int hgroups;             // ceil(nh_k / hp)
+    // several layers of a cache in one launch (grid z = layer * bs + b): element strides between the layers' window
+    // buffers, page tables and length rows; one layer: 0
+    long long x_ls, ids_ls, len_ls;
+    int n_layers;
+    int advance;             // 0: encode only (encode-ahead: the lengths move later, million_lengths_advance)
 };
 
 template <int DM>
 __global__ __launch_bounds__(kFlushWaves * 64) void pq_flush_kernel(FlushParams f) {
-    __shared__ float rows[256 * DM];
+    typedef f16 hvec __attribute__((ext_vector_type(DM)));
+    __shared__ __attribute__((aligned(16))) float rows[256 * DM];
     __shared__ float cand_d[kFlushWaves][64];
     __shared__ int cand_c[kFlushWaves][64];
     const int M = f.k.M;
@@ -239,117 +253,159 @@ __global__ __launch_bounds__(kFlushWaves * 64) void pq_flush_kernel(FlushParams 
     const bool vside = side_m >= M;                              // workgroup-uniform
     const EncParams &p = vside ? f.v : f.k;
     const int m = vside ? side_m - M : side_m;
-    const int b = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // grid z covers the (layer, request) pairs - all of them at once (a flush the attention waits for), or a slice that the
+    // workgroups walk (encode-ahead: about one workgroup per CU in flight, see launch_flush)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hp = f.hp;
-    const int parts = kFlushWaves / hp;                          // >= 1 (host: hp <= 16)
-    const int hl = w % hp, part = w / hp;                        // waves beyond hp * parts idle
+    const int parts = kFlushWaves / hp;                          // 1, 2 or 4
+    const int hl = w % hp, part = w / hp;
     const int hk = hgrp * hp + hl;
-    const bool active = part < parts && hk < p.nh_k;             // wave-uniform
+    const bool active = hk < p.nh_k;                             // wave-uniform
+    const int hkc = active ? hk : p.nh_k - 1;
     const int C = p.C;
-    // (1) independent of the lengths: this subspace's codebook row (one element per thread)
-    const f16 *cm = p.cents + (long long)m * C * DM;
-    f16 cv = (f16)0.f;
-    if ((int)threadIdx.x < C * DM) cv = cm[threadIdx.x];
-    // (2) lengths -> window row of this lane and the page id of the destination token, one round trip
-    int tok0 = p.tok0, xrow_start = p.xrow_start;
-    if (p.dev_lengths) {
-        tok0 = p.dev_lengths[b * 4 + 0]; xrow_start = p.dev_lengths[b * 4 + 2];
-        // ragged batches: only the requests whose window is full are flushed (every workgroup of item b decides alike,
-        // before any barrier and before the ticket)
-        if (f.min_r > 0 && p.dev_lengths[b * 4 + 1] < f.min_r) return;
-    }
-    // device-resident values are not trusted (cf. clamp_lengths): a start outside the ring becomes 0, a destination
-    // outside the page table drops the store
-    if (p.xrow_mod > 0 && (unsigned)xrow_start >= (unsigned)p.xrow_mod) xrow_start = 0;
-    const int t = blockIdx.x * 64 + lane;
-    const bool valid = t < p.n;
-    const int tc = valid ? t : p.n - 1;
-    int xrow = xrow_start + tc;
-    if (p.xrow_mod > 0) xrow %= p.xrow_mod;
-    const int hkc = hk < p.nh_k ? hk : p.nh_k - 1;
-    const f16 *xp = p.x + b * p.xsb + hkc * p.xsh + (long long)xrow * p.xsn + m * DM;
-    float x[DM];
+    // (1) independent of the lengths, and the same for every layer: this subspace's codebook row, one centroid per
+    //     thread (clamped, not predicated) -> LDS as fp32
+    {
+        const hvec cv = *(const hvec *)(p.cents + ((long long)m * C + (tid < C ? tid : C - 1)) * DM);
+        if (tid < C) {
 #pragma unroll
-    for (int k = 0; k < DM; ++k) x[k] = (float)xp[k];
-    const int tok = tok0 + t;
-    const int page = tok / p.page_size;
-    const bool tok_ok = valid && tok0 >= 0 && page < p.n_pages_cap;
-    const long long pid = p.page_ids[(long long)(b * p.nh_k + hkc) * p.n_pages_cap + (tok_ok ? page : 0)];
-    // (3) codebook row -> LDS as fp32
-    if ((int)threadIdx.x < C * DM) rows[threadIdx.x] = (float)cv;
-    for (int e = threadIdx.x + kFlushWaves * 64; e < C * DM; e += kFlushWaves * 64) rows[e] = (float)cm[e];
-    // every wave has its lengths in registers before the barrier lets thread 0 take the ticket
-    asm volatile("" :: "s"(tok0), "s"(xrow_start) : "memory");
-    __syncthreads();
-    int ticket = -1;
-    if (f.dev_lengths_w && threadIdx.x == 0)
-        ticket = __hip_atomic_fetch_add(f.dev_lengths_w + b * 4 + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (4) scan this wave's part of the centroids
+            for (int k = 0; k < DM; ++k) rows[tid * DM + k] = (float)cv[k];
+        }
+    }
     const int cq = (C + parts - 1) / parts;
     const int c0 = part * cq, c1 = min(c0 + cq, C);
-    float best = INFINITY;
-    int best_c = c0 < C ? c0 : 0;
-    if (active) {
-#pragma unroll 8
-        for (int c = c0; c < c1; ++c) {
-            float acc = 0.f;
+    for (int zi = blockIdx.z; zi < f.n_layers * p.bs; zi += gridDim.z) {
+        const int layer = zi / p.bs, b = zi % p.bs;
+        const int *const dev_lengths = p.dev_lengths ? p.dev_lengths + layer * f.len_ls : nullptr;
+        // (2) lengths (scalar cache) -> window row of this lane and the page id of the destination token, one round trip
+        int tok0 = p.tok0, xrow_start = p.xrow_start;
+        if (dev_lengths) {
+            tok0 = dev_lengths[b * 4 + 0]; xrow_start = dev_lengths[b * 4 + 2];
+            // ragged batches: only the requests whose window is full are flushed (every workgroup of item b decides
+            // alike, before any barrier and before the ticket)
+            if (f.min_r > 0 && dev_lengths[b * 4 + 1] < f.min_r) continue;
+        }
+        // device-resident values are not trusted (cf. clamp_lengths): a start outside the ring becomes 0, a destination
+        // outside the page table drops the store
+        if (p.xrow_mod > 0 && (unsigned)xrow_start >= (unsigned)p.xrow_mod) xrow_start = 0;
+        float x[DM];
+        {
+            const int t = blockIdx.x * 64 + lane;
+            int xrow = xrow_start + (t < p.n ? t : p.n - 1);
+            if (p.xrow_mod > 0) xrow %= p.xrow_mod;
+            const hvec xv = *(const hvec *)(p.x + layer * f.x_ls + b * p.xsb + hkc * p.xsh + (long long)xrow * p.xsn + m * DM);
 #pragma unroll
-            for (int k = 0; k < DM; ++k) {
-                const float e = x[k] - rows[c * DM + k];
-                const float sq = e * e;
-                acc = (k == 0) ? sq : acc + sq;
+            for (int k = 0; k < DM; ++k) x[k] = (float)xv[k];
+        }
+        int pid;
+        {
+            const int page = (tok0 + (int)blockIdx.x * 64 + lane) / p.page_size;
+            const bool ok = tok0 >= 0 && page < p.n_pages_cap;
+            pid = p.page_ids[layer * f.ids_ls + (b * p.nh_k + hkc) * p.n_pages_cap + (ok ? page : 0)];      // < 2^31 entries per layer (host check)
+        }
+        // every wave has its lengths in registers (and, first layer, the codebook row is in LDS) before the barrier lets
+        // thread 0 take the ticket
+        asm volatile("" :: "s"(tok0), "s"(xrow_start) : "memory");
+        __syncthreads();
+        // returning atomic of thread 0 as an out-of-range-predicated buffer operation of every thread (a plain atomicrmw in
+        // a one-lane branch makes hipcc's atomic optimizer wait vmcnt(0) on the spot: wave 0 would start its scan a memory
+        // round trip late); null lengths: an empty descriptor, every lane out of range
+        int ticket;
+        {
+            int *const lw = f.dev_lengths_w ? f.dev_lengths_w + layer * f.len_ls + b * 4 : nullptr;
+            __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)lw, 0, lw ? 16 : 0, 0x00020000);
+            ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rl, tid == 0 ? 12 : (1 << 20), 0, 0);
+        }
+        // (3) scan this wave's part of the centroids
+        float best = INFINITY;
+        int best_c = c0 < C ? c0 : 0;
+        if (active) {
+#pragma unroll DM <= 2 ? 4 : 2       // <= 32 VGPRs up to d_m = 4 (see above)
+            for (int c = c0; c < c1; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < DM; ++k) {
+                    const float e = x[k] - rows[c * DM + k];
+                    const float sq = e * e;
+                    acc = (k == 0) ? sq : acc + sq;
+                }
+                best_c = acc < best ? c : best_c;
+                best = fminf(best, acc);
             }
-            best_c = acc < best ? c : best_c;
-            best = fminf(best, acc);
         }
-    }
-    cand_d[w][lane] = best;
-    cand_c[w][lane] = best_c;
-    __syncthreads();
-    if (active && part == 0 && tok_ok) {
-        // parts in centroid order, strict '<': the lowest index wins exact ties; an empty part left +inf
-        for (int j = 1; j < parts; ++j) {
-            const float dj = cand_d[j * hp + hl][lane];
-            if (dj < best) { best = dj; best_c = cand_c[j * hp + hl][lane]; }
+        if (parts > 1) {      // workgroup-uniform
+            cand_d[w][lane] = best;
+            cand_c[w][lane] = best_c;
+            __syncthreads();
+            if (part == 0) {
+                // parts in centroid order, strict '<': the lowest index wins exact ties; an empty part left +inf
+                for (int j = 1; j < parts; ++j) {
+                    const float dj = cand_d[j * hp + hl][lane];
+                    if (dj < best) { best = dj; best_c = cand_c[j * hp + hl][lane]; }
+                }
+            }
         }
-        const int off = tok % p.page_size;
-        if (p.layout == MILLION_CODES_KPAGES) p.dst[(pid * p.page_size + off) * p.M + m] = (uint8_t)best_c;
-        else p.dst[(pid * p.M + m) * p.page_size + off] = (uint8_t)best_c;
-    }
-    // (5) the workgroup whose ticket was the last one moves the window: every workgroup had read the lengths by then
-    if (ticket >= 0) {
-        const int total = (int)(gridDim.x * gridDim.y);              // workgroups that read batch item b's lengths
-        if (ticket == total - 1) {
-            int *dl = f.dev_lengths_w + b * 4;
-            const int cap_tok = p.n_pages_cap * p.page_size;
-            int T = dl[0], r = dl[1], st = dl[2];
-            T = T < 0 ? 0 : T;
-            T = T + f.n_flush > cap_tok ? cap_tok : T + f.n_flush;
-            r = r - f.n_flush < 0 ? 0 : r - f.n_flush;
-            st = (unsigned)st < (unsigned)f.rcap ? st : 0;
-            dl[0] = T;
-            dl[1] = r;
-            dl[2] = (st + f.n_flush) % f.rcap;
-            __hip_atomic_store(dl + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            const int t = blockIdx.x * 64 + lane;
+            const int tok = tok0 + t;
+            const bool tok_ok = t < p.n && tok0 >= 0 && tok / p.page_size < p.n_pages_cap;
+            if (active && part == 0 && tok_ok) {
+                const int off = tok % p.page_size;
+                if (p.layout == MILLION_CODES_KPAGES) p.dst[((long long)pid * p.page_size + off) * p.M + m] = (uint8_t)best_c;
+                else p.dst[((long long)pid * p.M + m) * p.page_size + off] = (uint8_t)best_c;
+            }
+        }
+        // (4) the workgroup whose ticket was the last one moves the window: every workgroup had read the lengths by then
+        if (f.dev_lengths_w && tid == 0) {
+            const int total = (int)(gridDim.x * gridDim.y);              // workgroups that read batch item b's lengths
+            if (ticket == total - 1) {
+                int *dl = f.dev_lengths_w + layer * f.len_ls + b * 4;
+                const int cap_tok = p.n_pages_cap * p.page_size;
+                int T = dl[0], r = dl[1], st = dl[2];
+                T = T < 0 ? 0 : T;
+                T = T + f.n_flush > cap_tok ? cap_tok : T + f.n_flush;
+                r = r - f.n_flush < 0 ? 0 : r - f.n_flush;
+                st = (unsigned)st < (unsigned)f.rcap ? st : 0;
+                dl[0] = T;
+                dl[1] = r;
+                dl[2] = (st + f.n_flush) % f.rcap;
+                __hip_atomic_store(dl + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
-int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, int min_r, hipStream_t s) {
-    if (k.n <= 0 || k.bs * k.nh_k <= 0) return MILLION_OK;
+int launch_flush(const EncParams &k, const EncParams &v, int *dev_lengths_w, int rcap, int min_r, const FlushLayers &ly,
+                 hipStream_t s) {
+    if (k.n <= 0 || k.bs * k.nh_k <= 0 || ly.n_layers <= 0) return MILLION_OK;
     if (k.C > 256) { set_error("flush: uint8 codes only (C=%d)", k.C); return MILLION_ERR_SHAPE; }
+    if ((long long)ly.n_layers * k.bs > 65535) { set_error("flush: %d layers x %d requests exceed the grid", ly.n_layers, k.bs); return MILLION_ERR_SHAPE; }
     FlushParams f;
-    f.k = k; f.v = v; f.dev_lengths_w = dev_lengths_w; f.n_flush = k.n; f.rcap = rcap; f.min_r = dev_lengths_w ? min_r : 0;
-    // kv heads per workgroup: as many as fit its 16 waves, halved while the grid would leave CUs idle
+    f.k = k; f.v = v; f.n_flush = k.n; f.rcap = rcap; f.min_r = k.dev_lengths ? min_r : 0;
+    f.dev_lengths_w = ly.advance ? dev_lengths_w : nullptr;      // encode-ahead: nothing to advance, no ticket
+    f.x_ls = ly.x_ls; f.ids_ls = ly.ids_ls; f.len_ls = ly.len_ls; f.advance = ly.advance; f.n_layers = ly.n_layers;
+    // (layer, request) pairs in flight.  A flush the attention waits for (advance): all of them.  Encode-ahead: as many as
+    // keep about ONE workgroup per CU in flight - the most that fits beside the attention workgroups (a second flush
+    // workgroup on a CU would hold the registers the next attention workgroup needs, and the attention launch would wait
+    // for it); the workgroups walk the remaining pairs.
+    const int pairs = ly.n_layers * k.bs;
+    // kv heads per workgroup: 4 (one per wave), 2 or 1 - halved while the grid would leave CUs idle (the waves then split
+    // the centroid range instead)
     const int tblocks = (k.n + 63) / 64;
-    int hp = k.nh_k < kFlushWaves ? k.nh_k : kFlushWaves;
+    int hp = k.nh_k >= 4 ? 4 : k.nh_k >= 2 ? 2 : 1;
     const int cus = device_cus();
-    while (hp > 1 && (long long)tblocks * 2 * k.M * ((k.nh_k + hp - 1) / hp) * k.bs < cus) hp = (hp + 1) / 2;
+    while (hp > 1 && (long long)tblocks * 2 * k.M * ((k.nh_k + hp - 1) / hp) * pairs < cus) hp /= 2;
     f.hp = hp;
     f.hgroups = (k.nh_k + hp - 1) / hp;
-    const dim3 grid(tblocks, 2 * k.M * f.hgroups, k.bs);
+    int gz = pairs;
+    if (!ly.advance) {
+        const long long per_pair = (long long)tblocks * 2 * k.M * f.hgroups;
+        gz = (int)(cus / per_pair);
+        gz = gz < 1 ? 1 : gz > pairs ? pairs : gz;
+    }
+    const dim3 grid(tblocks, 2 * k.M * f.hgroups, gz);
     switch (k.dm) {
         case 1: hipLaunchKernelGGL((pq_flush_kernel<1>), grid, dim3(kFlushWaves * 64), 0, s, f); break;
         case 2: hipLaunchKernelGGL((pq_flush_kernel<2>), grid, dim3(kFlushWaves * 64), 0, s, f); break;

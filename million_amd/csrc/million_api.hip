@@ -305,6 +305,20 @@ int million_pq_encode(const million_encode_desc *desc, const void *x, const void
 int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const void *v_rows, const void *k_cents,
                      const void *v_cents, void *k_pool, void *v_pool, const int32_t *page_ids, int32_t *dev_lengths,
                      int resid_cap, int min_r, million_stream_t stream) {
+    return million_pq_flush_layers(desc, k_rows, v_rows, k_cents, v_cents, k_pool, v_pool, page_ids, dev_lengths, resid_cap, min_r,
+                                   1, 0, 0, 0, 1, stream);
+}
+
+int million_pq_flush_layers(const million_encode_desc *desc, const void *k_rows, const void *v_rows, const void *k_cents,
+                            const void *v_cents, void *k_pool, void *v_pool, const int32_t *page_ids, int32_t *dev_lengths,
+                            int resid_cap, int min_r, int n_layers, int64_t rows_layer_stride, int64_t ids_layer_stride,
+                            int64_t lengths_layer_stride, int advance, million_stream_t stream) {
+    if (n_layers < 1 || rows_layer_stride < 0 || ids_layer_stride < 0 || lengths_layer_stride < 0 || (rows_layer_stride & 7)) {
+        set_error("flush: n_layers=%d, layer strides %lld / %lld / %lld (rows: multiple of 8 elements)", n_layers,
+                  (long long)rows_layer_stride, (long long)ids_layer_stride, (long long)lengths_layer_stride);
+        return MILLION_ERR_ARG;
+    }
+    if (n_layers > 1 && desc && desc->dev_lengths && lengths_layer_stride < 4LL * desc->bs) { set_error("flush: lengths_layer_stride < 4 bs"); return MILLION_ERR_ARG; }
     EncParams k, v;
     int rc = fill_enc_params("flush", desc, k_rows, k_cents, k_pool, page_ids, k);
     if (rc != MILLION_OK) return rc;
@@ -316,7 +330,8 @@ int million_pq_flush(const million_encode_desc *desc, const void *k_rows, const 
     if ((const int32_t *)dev_lengths != desc->dev_lengths) { set_error("flush: dev_lengths must equal desc->dev_lengths (or both null)"); return MILLION_ERR_ARG; }
     v.layout = MILLION_CODES_VPAGES;
     if (min_r < 0 || min_r > resid_cap) { set_error("flush: min_r=%d outside [0, resid_cap]", min_r); return MILLION_ERR_ARG; }
-    return launch_flush(k, v, dev_lengths, resid_cap, min_r, (hipStream_t)stream);
+    const FlushLayers ly = {n_layers, (long long)rows_layer_stride, (long long)ids_layer_stride, (long long)lengths_layer_stride, advance ? 1 : 0};
+    return launch_flush(k, v, dev_lengths, resid_cap, min_r, ly, (hipStream_t)stream);
 }
 
 int million_pq_decode(const void *codes, const void *cents, void *out, int64_t n_rows, int d, int M, int C,

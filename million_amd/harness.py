@@ -187,10 +187,10 @@ class PQBackend:
             return self.cache.prefill(q, k, v, layer)
 
     def begin_step(self):
-        """Start of a decode step: full windows of all layers are flushed ahead on the cache's side stream (not with the
-        section timers on: they want the flush as a section of its own)."""
-        if self.flush_ahead and self.timers is NO_TIMERS and self.cache.next_step_flushes():
-            self.cache.flush_ahead(use_dev_lengths=self.use_dev_lengths)
+        """Start of a decode step: the cache encodes the oldest window page ahead of its flush step / commits it
+        (PagedPQCache.begin_step; not with the section timers on: they want the flush as a section of its own)."""
+        if self.flush_ahead and self.timers is NO_TIMERS:
+            self.cache.begin_step(use_dev_lengths=self.use_dev_lengths)
 
     def attend(self, layer, q, k, v):
         if self.timers is not NO_TIMERS and self.cache.residualed_tokens[layer] >= self.cache.extended_residual_size:
@@ -298,8 +298,8 @@ class LlamaShapeDecoder:
 
 
 class GraphedPQDecoder:
-    """The whole decode step (all layers + lm_head + argmax + token feedback) captured in two hipGraphs —
-    a plain step and a step whose layers flush a page first; lengths live on the device
+    """The whole decode step (all layers + lm_head + argmax + token feedback) captured in one hipGraph per kind of step
+    (PagedPQCache.next_step_kind: plain, encode-ahead riding along, commit, in-line flush); lengths live on the device
     (PagedPQCache.lengths), so a replay touches no host state."""
 
     def __init__(self, model: LlamaShapeDecoder, backend: PQBackend, tokens: torch.Tensor, pos: torch.Tensor):
@@ -313,9 +313,10 @@ class GraphedPQDecoder:
         self._eager_step()                     # allocates workspaces, warms hipBLASLt heuristics
         torch.cuda.synchronize()
         self.graphs = {}
-        r_now = int(st[1][0][0])
-        for name, r_cap in (("plain", r_now if r_now < cap else 0), ("flush", cap)):
-            cache.set_host_state((st[0], [r_cap] * L, st[2], st[3]))
+        for name, state in cache.capture_states(st):
+            cache.set_host_state(state)
+            if cache.next_step_kind() != name:      # e.g. requests at different lengths: no encode-ahead, hence no 'pre' / 'commit'
+                continue
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 self._eager_step()
@@ -334,8 +335,9 @@ class GraphedPQDecoder:
 
     def step(self):
         cache = self.be.cache
-        self.graphs["flush" if cache.next_step_flushes() else "plain"].replay()
-        cache.note_replayed_step()
+        kind = cache.next_step_kind()
+        self.graphs[kind].replay()
+        cache.note_replayed_step(kind)
         return self.tokens
 
 

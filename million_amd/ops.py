@@ -148,12 +148,26 @@ def pq_encode(X: torch.Tensor, cents: torch.Tensor) -> torch.Tensor:
 
 def pq_flush(k_rows: torch.Tensor, v_rows: torch.Tensor, k_cents: torch.Tensor, v_cents: torch.Tensor,
              k_pool: torch.Tensor, v_pool: torch.Tensor, page_ids: torch.Tensor, *, n: int, page_size: int,
-             token_start: int = 0, x_row_start: int = 0, dev_lengths: Optional[torch.Tensor] = None, min_r: int = 0) -> None:
+             token_start: int = 0, x_row_start: int = 0, dev_lengths: Optional[torch.Tensor] = None, min_r: int = 0,
+             advance: bool = True) -> None:
     """One launch per window flush (reference PagedPQCache.flush_to_pages, paged_pq_utils.py:130-210): encode the oldest n
     rows of the K and V windows (rings of k_rows.shape[2] rows) into a K page and a transposed V page; with dev_lengths
     the destination token and the ring start are read on the device and advanced there; min_r > 0 then skips the batch
-    items whose window holds fewer rows (ragged batches: only the full windows flush)."""
+    items whose window holds fewer rows (ragged batches: only the full windows flush).
+
+    Several layers in one launch: k_rows / v_rows (layers, bs, nh_k, cap, d), page_ids (layers, bs, nh_k, n_pages_cap),
+    dev_lengths (layers, bs, 4) - the layers of one cache allocated side by side.  advance=False: encode only (encode-ahead;
+    the window moves later: lengths_advance)."""
     _need_cuda(k_rows, v_rows, k_cents, v_cents, k_pool, v_pool, page_ids, dev_lengths)
+    n_layers, x_ls, ids_ls, len_ls = 1, 0, 0, 0
+    if k_rows.dim() == 5:
+        if page_ids.dim() != 4 or page_ids.shape[0] != k_rows.shape[0] or (dev_lengths is not None and (dev_lengths.dim() != 3 or dev_lengths.shape[0] != k_rows.shape[0])):
+            raise RuntimeError("pq_flush: layered windows need layered page_ids (and dev_lengths)")
+        if k_rows.stride(0) != v_rows.stride(0) or not page_ids.is_contiguous() or (dev_lengths is not None and not dev_lengths.is_contiguous()):
+            raise RuntimeError("pq_flush: layered windows must share the layer stride; contiguous page_ids / dev_lengths")
+        n_layers, x_ls, ids_ls = k_rows.shape[0], k_rows.stride(0), page_ids.stride(0)
+        len_ls = dev_lengths.stride(0) if dev_lengths is not None else 0
+        k_rows, v_rows, page_ids = k_rows[0], v_rows[0], page_ids[0]
     if k_rows.shape != v_rows.shape or k_rows.stride() != v_rows.stride() or k_rows.dtype != torch.float16 or v_rows.dtype != torch.float16:
         raise RuntimeError("pq_flush: K and V windows must be fp16 with the same shape and strides")
     if k_rows.dim() != 4 or k_rows.stride(3) != 1:
@@ -173,9 +187,10 @@ def pq_flush(k_rows: torch.Tensor, v_rows: torch.Tensor, k_cents: torch.Tensor, 
     desc.dst_layout, desc.dst_token_start = L.MILLION_CODES_KPAGES, token_start
     desc.page_size, desc.n_pages_cap = page_size, page_ids.shape[2]
     desc.dev_lengths = _ptr(dev_lengths)
-    L.check(L.load().million_pq_flush(ctypes.byref(desc), k_rows.data_ptr(), v_rows.data_ptr(), k_cents.data_ptr(),
-                                      v_cents.data_ptr(), k_pool.data_ptr(), v_pool.data_ptr(), page_ids.data_ptr(),
-                                      _ptr(dev_lengths), cap, min_r if dev_lengths is not None else 0, _stream()), "million_pq_flush")
+    L.check(L.load().million_pq_flush_layers(ctypes.byref(desc), k_rows.data_ptr(), v_rows.data_ptr(), k_cents.data_ptr(),
+                                             v_cents.data_ptr(), k_pool.data_ptr(), v_pool.data_ptr(), page_ids.data_ptr(),
+                                             _ptr(dev_lengths), cap, min_r if dev_lengths is not None else 0,
+                                             n_layers, x_ls, ids_ls, len_ls, int(bool(advance)), _stream()), "million_pq_flush_layers")
 
 
 def transpose_v_codes(v_codes: torch.Tensor, n_tokens: Optional[int] = None) -> torch.Tensor:

@@ -375,16 +375,24 @@ class PagedPQCache(_CacheBase):
         self.key_page_pool = z(total, self.page_size, self.M, dt=torch.uint8)
         self.value_page_pool = z(total, self.M, self.page_size, dt=torch.uint8)
         self.page_manager = PageManager(self.page_size, initial_pages=total, max_pages=total, M=self.M)
-        self.page_ids = [z(self.bs, nk, self.n_pages_cap, dt=torch.int32) for _ in range(self.layer_num)]
-        self.key_residual_cache = [z(self.bs, nk, cap, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
-        self.value_residual_cache = [z(self.bs, nk, cap, self.d, dt=self.scalar_t) for _ in range(self.layer_num)]
-        self.lengths = [z(self.bs, 4, dt=torch.int32) for _ in range(self.layer_num)]     # device mirror
+        # the layers' page tables, windows and length rows lie side by side (one allocation each; the per-layer lists are
+        # views): one launch can then serve every layer (begin_step: encode-ahead, commit)
+        self._page_ids_all = z(self.layer_num, self.bs, nk, self.n_pages_cap, dt=torch.int32)
+        self._kres_all = z(self.layer_num, self.bs, nk, cap, self.d, dt=self.scalar_t)
+        self._vres_all = z(self.layer_num, self.bs, nk, cap, self.d, dt=self.scalar_t)
+        self._lengths_all = z(self.layer_num, self.bs, 4, dt=torch.int32)
+        self.page_ids = [self._page_ids_all[l] for l in range(self.layer_num)]
+        self.key_residual_cache = [self._kres_all[l] for l in range(self.layer_num)]
+        self.value_residual_cache = [self._vres_all[l] for l in range(self.layer_num)]
+        self.lengths = [self._lengths_all[l] for l in range(self.layer_num)]     # device mirror
         # host mirrors, (layers, requests)
         zi = lambda: np.zeros((self.layer_num, self.bs), dtype=np.int64)
         self._seen_a, self._r_a, self._T_a, self._rs_a, self._pages_a = zi(), zi(), zi(), zi(), zi()
+        self._pre_a = zi()      # 1: the oldest page_size window rows are already encoded at tokens [T, T + page_size) (begin_step)
+        self._pre_join = False
         self._host_pids = [[[[] for _ in range(nk)] for _ in range(self.bs)] for _ in range(self.layer_num)]
         self._ws = None
-        self._side, self._flush_events = None, {}
+        self._side, self._flush_events, self._ahead = None, {}, None
         if self.preallocate:
             for l in range(self.layer_num):
                 for b in range(self.bs):
@@ -477,7 +485,7 @@ class PagedPQCache(_CacheBase):
                         self.page_manager.free_page(pid)
                     self._host_pids[l][b][h] = []
                 self._pages_a[l, b] = 0
-            self._T_a[l, b] = self._r_a[l, b] = self._rs_a[l, b] = self._seen_a[l, b] = 0
+            self._T_a[l, b] = self._r_a[l, b] = self._rs_a[l, b] = self._seen_a[l, b] = self._pre_a[l, b] = 0
             self.lengths[l][b].zero_()
 
     reset_request = release
@@ -553,14 +561,109 @@ class PagedPQCache(_CacheBase):
             self._T_a[layer_idx, b] += ps
             self._r_a[layer_idx, b] -= ps
             self._rs_a[layer_idx, b] = (self._rs_a[layer_idx, b] + ps) % cap
+            self._pre_a[layer_idx, b] = 0      # (rows encoded ahead were encoded again: same codes, same pages)
 
-    def flush_ahead(self, use_dev_lengths=False):
-        """Flush the full windows of ALL layers now, on a side stream, instead of layer by layer in front of each layer's
-        attention: a layer's window rows and lengths do not depend on the current step's computation, so the 32 flush
-        launches of a flush step (9.5 us each, dependent chains of small loads) run beside the attention launches of the
-        layers before them; decoding_with_pages(layer) then only waits for its layer's flush event.  Call it at the start of
-        a decode step (next_step_flushes() says when); every layer must then be decoded in this step (the side stream is
-        joined layer by layer - also inside a hipGraph capture, where this becomes a fork / join of graph branches).
+    # ---- encode-ahead: the flush without a flush step ---------------------------------------------------------------
+    # The reference flushes the oldest page_size window rows when the window is full (paged_pq_utils.py:359-361).  Those
+    # rows are complete page_size steps after the previous flush - extended_residual_size - page_size steps BEFORE they
+    # are flushed - and never change again, and a PQ code depends on nothing but its row and the codebook.  begin_step()
+    # therefore encodes them early: ONE launch for all layers (million_pq_flush_layers, advance = 0) on a side stream,
+    # in a step that needs nothing from it, next to that step's attention launches (the kernel's 4-wave, <= 32-register
+    # workgroups fit on a CU beside an attention workgroup; nobody waits for it before the end of the step).  The flush
+    # step itself is then a commit: the lengths move (host mirror; device mirror: one million_lengths_advance launch for
+    # all layers) and no code is computed.  Codes, pages and lengths after the commit are exactly those of the in-line
+    # flush; whatever cannot be served this way (requests at different lengths, a step that was skipped) falls back to it.
+    def next_step_kind(self) -> str:
+        """'plain' | 'pre' (encode-ahead rides along) | 'commit' (flush step, codes already there) | 'flush' (flush step)."""
+        cap = self.extended_residual_size
+        full = self._r_a >= cap
+        if full.any():
+            return "commit" if full.all() and self._pre_a.all() else "flush"
+        if (not self._pre_a.all() and self._r_a[0, 0] >= self.encode_ahead_at() and self._r_a[0, 0] >= self.page_size
+                and self._all_lockstep()):
+            groups = self._ea_groups()
+            for gi, (g0, g1) in enumerate(groups):
+                if not self._pre_a[g0:g1].all():
+                    return "pre" if len(groups) == 1 else f"pre{gi}"
+        return "plain"
+
+    def _ea_groups(self):
+        """Layer ranges encoded ahead per step: all layers in one step up to 32 (layer, request) pairs, else spread over
+        consecutive steps (at 8 requests the attention launches leave few idle issue slots: all layers in one step made
+        that step 1.6 x a plain one; 4 layers per step over 8 steps: see DESIGN.md 4.4)."""
+        n = getattr(self, "encode_ahead_steps", None)
+        if n is None:
+            n = -(-self.bs * self.layer_num // 32)
+        n = max(1, min(int(n), self.layer_num, max(1, self.page_size - 16)))
+        per = -(-self.layer_num // n)
+        return [(g0, min(g0 + per, self.layer_num)) for g0 in range(0, self.layer_num, per)]
+
+    def encode_ahead_at(self) -> int:
+        """Window fill at which the oldest page is encoded ahead (a few steps after the previous flush)."""
+        return self.extended_residual_size - self.page_size + min(8, max(self.page_size // 8, 1))
+
+    def _all_lockstep(self) -> bool:
+        return all((a == a[0, 0]).all() for a in (self._T_a, self._r_a, self._rs_a))
+
+    def begin_step(self, use_dev_lengths=False) -> str:
+        """Call at the start of every decode step, before layer 0 (then decode every layer, in order).  Returns the kind of
+        the step (next_step_kind).  Without it decoding_with_pages flushes in line, as the reference does."""
+        kind = self.next_step_kind()
+        cap, ps = self.extended_residual_size, self.page_size
+        if kind == "commit":
+            if use_dev_lengths:
+                ops.lengths_advance(self._lengths_all.view(-1, 4), ps, cap)      # every layer, every request: one launch
+            self._T_a += ps
+            self._r_a -= ps
+            self._rs_a[:] = (self._rs_a + ps) % cap
+            self._pre_a[:] = 0
+        elif kind == "flush":
+            self.flush_ahead(use_dev_lengths=use_dev_lengths)
+        elif kind.startswith("pre"):
+            groups = self._ea_groups()
+            G0, G1 = groups[int(kind[3:] or 0)]
+            T = int(self._T_a[0, 0])
+            if not self.preallocate:
+                for l in range(G0, G1):
+                    for b in range(self.bs):
+                        self._assign_pages(l, (T + ps + ps - 1) // ps, b)
+            elif T + ps > self.max_tokens:
+                return "plain"      # the flush step will raise, as before
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(main)      # behind the appends of the previous step (the rows themselves are older)
+            with torch.cuda.stream(self._side):
+                # a grid of ONE layer's size whose workgroups walk the layers (one flush workgroup per CU at a time: what fits
+                # beside an attention workgroup), in `encode_ahead_launches` launches
+                nl_ = getattr(self, "encode_ahead_launches", None)
+                if nl_ is None:
+                    # replayed from a hipGraph: one launch per layer (the work trickles through the whole step: measured
+                    # 1.04 x a plain step against 1.09 x for one long launch); eager: one launch (the host pays per launch)
+                    nl_ = self.layer_num if torch.cuda.is_current_stream_capturing() else 1
+                nl_ = max(1, min(int(nl_), G1 - G0))
+                per = (G1 - G0 + nl_ - 1) // nl_
+                for g0 in range(G0, G1, per):
+                    g1 = min(g0 + per, G1)
+                    ops.pq_flush(self._kres_all[g0:g1], self._vres_all[g0:g1], self.key_cent, self.value_cent, self.key_page_pool,
+                                 self.value_page_pool, self._page_ids_all[g0:g1], n=ps, page_size=ps, token_start=T,
+                                 x_row_start=int(self._rs_a[0, 0]),
+                                 dev_lengths=self._lengths_all[g0:g1] if use_dev_lengths else None,
+                                 min_r=ps if use_dev_lengths else 0, advance=False)
+            self._pre_a[G0:G1] = 1
+            self._pre_join = True      # joined behind the last layer's attention (decoding_with_pages)
+        return kind
+
+    def flush_ahead(self, use_dev_lengths=False, depth=2):
+        """Flush the full windows of this step on a side stream instead of in front of each layer's attention: a layer's
+        window rows and lengths do not depend on the current step's computation, so its flush launch (a 4-wave, 21-register
+        kernel that fits on a CU beside an attention workgroup) runs under the attention launches of the layers before
+        it; decoding_with_pages(layer) only waits for its own layer's flush event.  Call it at the start of a decode step
+        (next_step_flushes() says when); every layer must then be decoded in this step, in order (the side stream is
+        joined layer by layer - inside a hipGraph capture this becomes a fork / join of graph branches).
+        The launches are issued `depth` layers ahead of the attention that needs them, not all at once: the host (and a
+        replayed hipGraph, which submits its nodes in capture order) otherwise spends 32 flush submissions before the
+        first attention launch gets out - measured: the main branch of the replayed step started ~300 us late.
         Results are identical to the in-line flush."""
         cap = self.extended_residual_size
         todo = [l for l in range(self.layer_num) if (self._r_a[l] >= cap).any()]
@@ -568,15 +671,36 @@ class PagedPQCache(_CacheBase):
             return
         main = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device)      # (a high-priority side stream changes nothing: measured)
             self._flush_events = {}
         self._side.wait_stream(main)      # fork: behind everything this stream has queued (the previous step's appends)
-        with torch.cuda.stream(self._side):
-            for l in todo:
-                self.flush_to_pages(l, use_dev_lengths=use_dev_lengths)
+        self._ahead = (todo, use_dev_lengths, max(1, int(depth)))
+        self._ahead_issue(upto_layer=-1)
+
+    def _ahead_issue(self, upto_layer):
+        """Issue the pending side-stream flushes of the layers <= upto_layer + depth (in layer order)."""
+        todo, use_dl, depth = self._ahead
+        n = 0
+        while n < len(todo) and todo[n] <= upto_layer + depth:
+            n += 1
+        if n:
+            if upto_layer >= 0:
+                # behind the attention launches issued so far (layers < upto_layer): a graph replay submits its nodes in
+                # an order of the runtime's choosing - without this edge ROCm submitted the whole flush chain before the
+                # first attention node (main branch ~300 us late); with it any topological order interleaves the two
+                # chains.  The flush then has the attention launches of layers upto_layer .. upto_layer + depth - 1 to hide under.
                 ev = torch.cuda.Event()
-                ev.record(self._side)
-                self._flush_events[l] = ev
+                ev.record(torch.cuda.current_stream())
+                self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                for l in todo[:n]:
+                    self.flush_to_pages(l, use_dev_lengths=use_dl)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    self._flush_events[l] = ev
+            del todo[:n]
+        if not todo:
+            self._ahead = None
 
     def decoding_with_pages(self, query_states, key_states, value_states, layer_idx, out=None, use_dev_lengths=False):
         """One decode step of one layer (paged_pq_utils.py:341-386): flush if the window is full, append the
@@ -584,6 +708,8 @@ class PagedPQCache(_CacheBase):
         is read on the device (the host mirror is still advanced), which makes the call graph-capturable and lets
         requests of different lengths share the launch."""
         cap = self.extended_residual_size
+        if getattr(self, "_ahead", None) is not None:
+            self._ahead_issue(upto_layer=layer_idx)                                      # keep the side stream `depth` layers ahead
         ev = self._flush_events.pop(layer_idx, None) if getattr(self, "_side", None) is not None else None
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)                                   # flushed ahead on the side stream
@@ -601,13 +727,17 @@ class PagedPQCache(_CacheBase):
         self._r_a[layer_idx] += 1
         self._seen_a[layer_idx] += 1
         # append (:377-380) + attention (:386) in ONE launch: the new row is attended to and parked in the window
-        return ops.pq_decode_attn(query_states, self.key_page_pool, self.value_page_pool, self._kprep, self._vprep,
-                                  self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], r,
-                                  k_new=key_states, v_new=value_states,
-                                  M=self.M, C=self.C, n_tokens=self.max_tokens if use_dev_lengths else int(self._T_a[layer_idx, 0]),
-                                  resid_start=rs, k_page_ids=self.page_ids[layer_idx],
-                                  v_page_ids=self.page_ids[layer_idx], page_size=self.page_size, out=out,
-                                  dev_lengths=dl, workspace=self._ws)
+        res = ops.pq_decode_attn(query_states, self.key_page_pool, self.value_page_pool, self._kprep, self._vprep,
+                                 self.key_residual_cache[layer_idx], self.value_residual_cache[layer_idx], r,
+                                 k_new=key_states, v_new=value_states,
+                                 M=self.M, C=self.C, n_tokens=self.max_tokens if use_dev_lengths else int(self._T_a[layer_idx, 0]),
+                                 resid_start=rs, k_page_ids=self.page_ids[layer_idx],
+                                 v_page_ids=self.page_ids[layer_idx], page_size=self.page_size, out=out,
+                                 dev_lengths=dl, workspace=self._ws)
+        if self._pre_join and layer_idx == self.layer_num - 1:
+            torch.cuda.current_stream().wait_stream(self._side)      # the step's encode-ahead launch ends with the step
+            self._pre_join = False
+        return res
 
     # the reference's non-paged entry point keeps working on the paged store
     decoding = decoding_with_pages
@@ -619,21 +749,47 @@ class PagedPQCache(_CacheBase):
     def host_state(self):
         """(seen, r, T, resid_start), each (layers, requests) - what set_host_state takes back (it also takes one value per
         layer for all requests)."""
-        return (self._seen_a.copy(), self._r_a.copy(), self._T_a.copy(), self._rs_a.copy())
+        return (self._seen_a.copy(), self._r_a.copy(), self._T_a.copy(), self._rs_a.copy(), self._pre_a.copy())
 
     def set_host_state(self, st):
+        """(seen, r, T, resid_start[, encoded-ahead flags]); four entries: the flags are cleared."""
         for arr, v in zip((self._seen_a, self._r_a, self._T_a, self._rs_a), st):
             self._set_rows(arr, v)
+        self._pre_a[:] = 0
+        if len(st) > 4:
+            self._set_rows(self._pre_a, st[4])
+
+    def capture_states(self, st=None):
+        """[(kind, host state)] - one host state per kind of step, for capturing one hipGraph per kind with device-resident
+        lengths (begin_step + all layers).  st: the state to derive them from (default: now)."""
+        st = self.host_state() if st is None else st
+        L_, cap = self.layer_num, self.extended_residual_size
+        r_now = int(st[1][0][0])
+        r_plain = r_now if r_now < cap else 0
+        groups = self._ea_groups()
+        pre = [("pre" if len(groups) == 1 else f"pre{gi}",
+                (st[0], [self.encode_ahead_at() + gi] * L_, st[2], st[3], [1 if l < g0 else 0 for l in range(L_)]))
+               for gi, (g0, g1) in enumerate(groups)]
+        return [("plain", (st[0], [r_plain] * L_, st[2], st[3], [1] * L_))] + pre + [
+                ("commit", (st[0], [cap] * L_, st[2], st[3], [1] * L_)),
+                ("flush", (st[0], [cap] * L_, st[2], st[3], [0] * L_))]
 
     def next_step_flushes(self, layer_idx: int = 0) -> bool:
         return bool((self._r_a[layer_idx] >= self.extended_residual_size).any())
 
-    def note_replayed_step(self):
+    def note_replayed_step(self, kind=None):
+        """The host-mirror transitions of one replayed step of the given kind (default: next_step_kind())."""
+        kind = self.next_step_kind() if kind is None else kind
         cap, ps = self.extended_residual_size, self.page_size
-        full = self._r_a >= cap
-        self._T_a[full] += ps
-        self._r_a[full] -= ps
-        self._rs_a[full] = (self._rs_a[full] + ps) % cap
+        if kind in ("commit", "flush"):
+            full = self._r_a >= cap
+            self._T_a[full] += ps
+            self._r_a[full] -= ps
+            self._rs_a[full] = (self._rs_a[full] + ps) % cap
+            self._pre_a[full] = 0
+        elif kind.startswith("pre"):
+            g0, g1 = self._ea_groups()[int(kind[3:] or 0)]
+            self._pre_a[g0:g1] = 1
         self._r_a += 1
         self._seen_a += 1
 

@@ -633,6 +633,97 @@ def test_paged_cache_pipeline(use_dl, env, oracle):
         assert cache.lengths[0].cpu().numpy()[:, :2].tolist() == [[cache._T[0], cache.residualed_tokens[0]]] * bs
 
 
+@pytest.mark.parametrize("mode", ["host-lengths", "device-lengths", "graphs", "on-demand", "spread", "spread-graphs"])
+def test_paged_cache_encode_ahead_equals_inline_flush(mode, env, oracle):
+    """PagedPQCache.begin_step: the oldest window page of all layers is encoded by ONE launch (million_pq_flush_layers,
+    advance = 0) a few steps after the previous flush, the flush step only commits the lengths.  Same codes, same pages,
+    same lengths and bit-identical attention outputs as the in-line flush of the reference's schedule
+    (paged_pq_utils.py:359-361), over two flush periods; every kind of step occurs; 'graphs': one hipGraph per kind of
+    step with device-resident lengths, replayed."""
+    torch, ops = env
+    from million_amd.pq_cache import PagedPQCache
+    bs, nh, nhk, d, M, C, ps, L_ = 2, 8, 2, 128, 64, 256, 64, 3
+    n_prompt, n_dec = 700, 200      # the window fills at step 128, then every 64 steps: two flush periods
+    rs = np.random.RandomState(21)
+    ck, cv = rs.standard_normal((M, C, 2)).astype(np.float16), rs.standard_normal((M, C, 2)).astype(np.float16)
+    K = rs.standard_normal((L_, bs, nhk, n_prompt + n_dec, d)).astype(np.float16)
+    V = rs.standard_normal((L_, bs, nhk, n_prompt + n_dec, d)).astype(np.float16)
+    Q = rs.standard_normal((n_dec, L_, bs, nh, 1, d)).astype(np.float16)
+    Kd, Vd, Qd = torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda(), torch.from_numpy(Q).cuda()
+    use_dl = mode in ("device-lengths", "graphs", "spread-graphs")
+    spread = 2 if mode.startswith("spread") else 1      # the layers' encode-ahead over two steps (large batches do that)
+
+    def make():
+        c = PagedPQCache(bs=bs, nh=nh, num_key_value_heads=nhk, M=M, layer_num=L_, d=d, page_size=ps,
+                         extended_residual_size=128, max_tokens=n_prompt + n_dec + 256, preallocate=mode != "on-demand")
+        c.set_cent(torch.from_numpy(ck).cuda(), torch.from_numpy(cv).cuda())
+        for l in range(L_):
+            c.prefill(Qd[0, l].expand(-1, -1, 1, -1).repeat(1, 1, n_prompt, 1), Kd[l, :, :, :n_prompt].contiguous(),
+                      Vd[l, :, :, :n_prompt].contiguous(), l)
+        return c
+
+    ref, cache = make(), make()
+    cache.encode_ahead_steps = spread
+    kn = [torch.empty(bs, nhk, 1, d, device="cuda", dtype=torch.float16) for _ in range(L_)]
+    vn = [torch.empty_like(kn[0]) for _ in range(L_)]
+    qs = [torch.empty(bs, nh, 1, d, device="cuda", dtype=torch.float16) for _ in range(L_)]
+    outs = [torch.empty(bs, nh, 1, d, device="cuda", dtype=torch.float16) for _ in range(L_)]
+
+    def step():
+        cache.begin_step(use_dev_lengths=use_dl)
+        for l in range(L_):
+            cache.decoding_with_pages(qs[l], kn[l], vn[l], l, out=outs[l], use_dev_lengths=use_dl)
+
+    graphs = {}
+    if mode.endswith("graphs"):
+        st = cache.host_state()
+        dl_backup = cache._lengths_all.clone()
+        win = (cache._kres_all.clone(), cache._vres_all.clone())
+        step()                                   # eager once: allocates the workspace (restored below)
+        torch.cuda.synchronize()
+        for name, state in cache.capture_states(st):
+            cache.set_host_state(state)
+            assert cache.next_step_kind() == name
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            graphs[name] = g
+        cache.set_host_state(st)
+        cache._lengths_all.copy_(dl_backup)
+        cache._kres_all.copy_(win[0]); cache._vres_all.copy_(win[1])
+    kinds = []
+    for i in range(n_dec):
+        t = n_prompt + i
+        for l in range(L_):
+            kn[l].copy_(Kd[l, :, :, t:t + 1]); vn[l].copy_(Vd[l, :, :, t:t + 1]); qs[l].copy_(Qd[i, l])
+        want = [ref.decoding_with_pages(qs[l], kn[l], vn[l], l, use_dev_lengths=use_dl).clone() for l in range(L_)]
+        kind = cache.next_step_kind()
+        kinds.append(kind)
+        if mode.endswith("graphs"):
+            graphs[kind].replay()
+            cache.note_replayed_step(kind)
+        else:
+            step()
+        torch.cuda.synchronize()
+        for l in range(L_):
+            assert torch.equal(outs[l], want[l]), f"step {i} ({kind}) layer {l}"
+        assert (cache._T[0], cache.residualed_tokens[0], cache._rstart[0]) == (ref._T[0], ref.residualed_tokens[0], ref._rstart[0])
+    pre = [i for i, k in enumerate(kinds) if k.startswith("pre")]
+    assert len(pre) == 2 * spread and kinds.count("commit") == 2 and "flush" not in kinds
+    assert pre[spread - 1] < kinds.index("commit") < pre[spread]
+    if spread == 2:
+        assert [kinds[i] for i in pre] == ["pre0", "pre1"] * 2
+    T = ref._T[0]
+    assert T == n_prompt + 2 * ps
+    for l in range(L_):
+        rk, rv = ref._codes_rowmajor(l, T)
+        ck_, cv_ = cache._codes_rowmajor(l, T)
+        assert torch.equal(rk, ck_) and torch.equal(rv, cv_)
+        np.testing.assert_array_equal(ck_.cpu().numpy(), oracle.pq_encode(K[l, :, :, :T], ck))
+    if use_dl:
+        assert torch.equal(cache._lengths_all, ref._lengths_all)
+
+
 @pytest.mark.parametrize("G", [3, 5, 6, 7])
 def test_attn_odd_group_sizes(G, env, oracle):
     """GQA group sizes that are not powers of two (scalar last-arriver combine, partially filled MFMA columns)."""
@@ -1129,17 +1220,20 @@ def test_harness_pq_step_attention_against_oracle(env, oracle):
             return out
         be.attend = spy
         caps_of = None
-        if mode == "graph":      # ctor: one eager step, then the "plain" and the "flush" capture; a replay refreshes its clones
+        if mode == "graph":      # ctor: one eager step, then one capture per kind of step; a replay refreshes its clones
             gd = H.GraphedPQDecoder(model, be, tokens, pos)
-            assert len(captured) == 3 * nl
-            caps_of = {"plain": captured[nl:2 * nl], "flush": captured[2 * nl:3 * nl]}
+            names = [n for n, _ in cache.capture_states() if n in gd.graphs]
+            assert names == ["plain", "pre", "commit", "flush"] and len(captured) == (1 + len(names)) * nl
+            caps_of = {n: captured[(i + 1) * nl:(i + 2) * nl] for i, n in enumerate(names)}
         ck, cv = cache.key_cent.cpu().numpy(), cache.value_cent.cpu().numpy()
         for step in range(140):                                 # the window fills after 128 steps: one flush inside
-            flush = cache.next_step_flushes()
+            flush, kind = cache.next_step_flushes(), cache.next_step_kind()
             T, r, rs = cache._T[0], cache.residualed_tokens[0], cache._rstart[0]      # what the launches of this step read
             if flush:
                 T, r, rs = T + 64, r - 64, (rs + 64) % 128
-            check = step in (0, 1, 127, 128, 129, 139)
+            # the oldest page is encoded ahead at step 72 (PagedPQCache.begin_step), step 128 commits it
+            assert kind == {72: "pre", 128: "commit", 136: "pre"}.get(step, "plain")
+            check = step in (0, 1, 72, 73, 127, 128, 129, 139)
             if check:
                 win = [(cache.key_residual_cache[l].cpu().numpy().copy(), cache.value_residual_cache[l].cpu().numpy().copy())
                        for l in range(nl)]
@@ -1153,7 +1247,7 @@ def test_harness_pq_step_attention_against_oracle(env, oracle):
             if not check:
                 continue
             assert flush == (step == 128)
-            caps = caps_of["flush" if flush else "plain"] if mode == "graph" else list(captured)
+            caps = caps_of[kind] if mode == "graph" else list(captured)
             assert len(caps) == nl
             kpool, vpool = cache.key_page_pool.cpu().numpy(), cache.value_page_pool.cpu().numpy()
             for (layer, q, k, v, out) in caps:
