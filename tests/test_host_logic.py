@@ -314,3 +314,55 @@ def test_paged_cache_host_lifecycle_on_cpu():
     c.note_replayed_step()
     assert c._r_a.tolist() == [[128, 65], [1, 1], [65, 65]] and c._T_a.tolist() == [[0, 64], [0, 0], [64, 64]]
     assert c._rs_a.tolist() == [[0, 64], [0, 0], [64, 64]]
+
+
+def test_paged_cache_step_kinds_state_machine_on_cpu():
+    """PagedPQCache.next_step_kind / note_replayed_step / capture_states (the host side of encode-ahead, pq_cache.py):
+    plain steps, the encode-ahead step(s) a few steps after a flush, the commit step when the window is full, the in-line
+    flush as the fallback (requests at different lengths, flags lost); one capture state per kind reproduces its kind."""
+    from million_amd.pq_cache import PagedPQCache
+    c = PagedPQCache(bs=2, nh=8, num_key_value_heads=2, M=64, layer_num=4, d=128, page_size=64, extended_residual_size=128,
+                     max_tokens=4096, preallocate=False, device="cpu")
+    assert c.encode_ahead_at() == 72 and c._ea_groups() == [(0, 4)]
+    kinds = []
+    for _ in range(200):                         # empty window after a prefill: commits at steps 128 and 192
+        k = c.next_step_kind()
+        kinds.append(k)
+        c.note_replayed_step(k)
+    assert [i for i, k in enumerate(kinds) if k != "plain"] == [72, 128, 136, 192]
+    assert [kinds[i] for i in (72, 128, 136, 192)] == ["pre", "commit", "pre", "commit"]
+    assert c._T_a.tolist() == [[128, 128]] * 4 and c._r_a.tolist() == [[200 - 128] * 2] * 4
+    # spread over two steps (what large batches do by themselves: bs * layers > 32)
+    c.encode_ahead_steps = 2
+    assert c._ea_groups() == [(0, 2), (2, 4)]
+    kinds = []
+    for _ in range(64):
+        k = c.next_step_kind()
+        kinds.append(k)
+        c.note_replayed_step(k)
+    assert [k for k in kinds if k != "plain"] == ["pre0", "pre1", "commit"]
+    big = PagedPQCache(bs=8, nh=8, num_key_value_heads=2, M=64, layer_num=32, d=128, page_size=64, extended_residual_size=128,
+                       max_tokens=256, preallocate=False, device="cpu")
+    assert len(big._ea_groups()) == 8 and big._ea_groups()[0] == (0, 4)
+    # one capture state per kind, and each reproduces its kind
+    st = c.host_state()
+    names = []
+    for name, state in c.capture_states(st):
+        c.set_host_state(state)
+        assert c.next_step_kind() == name
+        names.append(name)
+    assert names == ["plain", "pre0", "pre1", "commit", "flush"]
+    c.set_host_state(st)
+    # fallbacks: a request at another length -> no encode-ahead; its window full without the flags -> in-line flush
+    c._r_a[:] = 100
+    c._pre_a[:] = 0
+    c._r_a[:, 1] = 90
+    assert c.next_step_kind() == "plain"
+    c._r_a[:, 1] = 128
+    assert c.next_step_kind() == "flush"
+    c._r_a[:] = 128
+    c._pre_a[:] = 1
+    c._pre_a[3, 1] = 0
+    assert c.next_step_kind() == "flush"
+    c.release(1)                                  # a recycled slot loses its flags with its lengths
+    assert c._pre_a[:, 1].tolist() == [0] * 4
