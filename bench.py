@@ -291,14 +291,17 @@ def main():
     mean_dur = sum(durs) / len(durs)
     med_dur = durs[len(durs) // 2]
     # the same launches back to back between ONE pair of events: launch-to-launch period, no per-launch event cost
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda._sleep(int(2.0e8))
-    e0.record()
-    for i in range(nl):
-        attn_launch(i % layers)
-    e1.record()
-    torch.cuda.synchronize()
-    period = e0.elapsed_time(e1) * 1e-3 / nl
+    periods = []
+    for _ in range(3):                         # three regions; the median is reported, all three are in the line
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(2.0e8))
+        e0.record()
+        for i in range(nl):
+            attn_launch(i % layers)
+        e1.record()
+        torch.cuda.synchronize()
+        periods.append(e0.elapsed_time(e1) * 1e-3 / nl)
+    period = sorted(periods)[1]
     alg = algorithmic_bytes(bs, nh, nhk, T_now, r_now, d, M, C)
     achieved = alg / period / 1e9
     traffic = None
@@ -355,7 +358,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "launch_us_mean": round(period * 1e6, 2),
-                         "launches_timed": nl, "timing": "HIP events around the region of back-to-back launches / launches",
+                         "launches_timed": nl, "timing": "HIP events around a region of back-to-back launches / launches; median of three regions",
+                         "launch_us_regions": [round(x * 1e6, 2) for x in periods],
                          "event_pair_per_launch_us_mean": round(mean_dur * 1e6, 2),
                          "event_pair_per_launch_us_median": round(med_dur * 1e6, 2)},
         }
@@ -450,7 +454,7 @@ def residual_tile_record(torch, attn_launch, layers, bs, nh, nhk, d, r, T):
             if not s.shape[0]:
                 continue
             d12 = (s[:, :, 2] - s[:, :, 1]) / 100.0                   # us per wave
-            us.append(float(d12[:, :4].mean()))                       # waves 0-3 carry the tiles at r ~ 100 over 32 splits
+            us.append(float(d12[:, 0].mean()))                        # wave 0 carries a split's rows (runs of 16: one tile at r ~ 100 over 32 splits)
             n_wgs = s.shape[0]
     finally:
         lib.million_debug_set_stamp_buffer(None)
@@ -459,7 +463,7 @@ def residual_tile_record(torch, attn_launch, layers, bs, nh, nhk, d, r, T):
     G = nh // nhk
     nsplit = max(1, n_wgs // (bs * nhk))
     rows_per_split = -(-r // nsplit)
-    waves_with_tile = min(8, rows_per_split) * n_wgs                   # a split's rows are dealt to its waves one by one
+    waves_with_tile = min(8, -(-rows_per_split // 16)) * n_wgs         # a split's rows go to its waves in runs of 16 (attn_mfma.hip: kResRows)
     issued = waves_with_tile * (4 * 16 * 16 * 32 * 2 + 4 * 32 * 32 * 16 * 2)
     useful = bs * nhk * r * d * G * 2 * 2
     t = sum(us) / len(us)

@@ -22,7 +22,16 @@ out.mkdir(exist_ok=True)
 KERNEL = "attn_"            # the fused decode-attention launch: attn_stream_kernel (attn_mfma_kernel: fallback)
 
 summary = {"kernel": KERNEL, "tag": tag}
-ks = glob.glob(str(src / "prof_kt" / "*" / "*_kernel_stats.csv"))
+import os
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: keep the latest run of each."""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+ks = newest(str(src / "prof_kt" / "*" / "*_kernel_stats.csv"))
 if ks:
     rows = list(csv.DictReader(open(ks[0])))
     keep = [r for r in rows if "million::" in r["Name"] or "_ZN7million" in r["Name"]]
@@ -39,7 +48,7 @@ if ks:
         summary["rocprof_calls"] = int(r["Calls"])
 pmc = defaultdict(list)
 for d in ("prof_fetch", "prof_write", "prof_sq"):
-    for f in glob.glob(str(src / d / "*" / "*_counter_collection.csv")):
+    for f in newest(str(src / d / "*" / "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if KERNEL in row["Kernel_Name"]:
                 pmc[row["Counter_Name"]].append(float(row["Counter_Value"]))
