@@ -1640,9 +1640,8 @@ bool attn_mfma_supported(const AttnParams &p) {
 static int g_mfma_policy = 0;
 void set_mfma_policy(int policy) { g_mfma_policy = policy; }
 
-int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
-    AttnParams p = p_in;
-    // split policy: about one workgroup per CU; a split is at least 512 tokens long
+// split policy: about one workgroup per CU; a split is at least 512 tokens long
+static int mfma_splits(const AttnParams &p) {
     const int cus = device_cus();
     const int bh = p.bs * p.nh_k;
     int ns = (cus + bh - 1) / bh;
@@ -1655,6 +1654,21 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     if (ns > units) ns = units;
     const int ns_window = (p.rcap + kNW * kResRows - 1) / (kNW * kResRows);      // splits the residual window needs
     if (ns < ns_window) ns = ns_window;      // (a split beyond the last unit just has no code units)
+    return ns;
+}
+// streaming kernel: rounds per wave = ceil(T / (ns * 256 tokens)) must fit the 64 page ids a wave preloads
+static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64; }
+
+// C = 128 runs on the streaming kernel only: without it (T = 0, more than 64 rounds per wave) the call goes back to the caller
+bool attn_mfma_handles(const AttnParams &p) {
+    return attn_mfma_supported(p) && (p.C != 128 || mfma_stream_ok(p, mfma_splits(p)));
+}
+
+int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
+    AttnParams p = p_in;
+    const int bh = p.bs * p.nh_k;
+    const int ns = mfma_splits(p);
+    const int units = p.T > 0 ? (p.T + 31) / 32 : 1;
     int len = 32 * ((units + ns - 1) / ns);
     p.nsplit = ns;
     p.nslots = ns;
@@ -1673,8 +1687,7 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
-    // streaming kernel: rounds per wave = ceil(T / (ns * 256 tokens)) must fit the 64 page ids a wave preloads
-    const bool stream_ok = p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64;
+    const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
     const dim3 grid(ns, bh), block(kNW * 64);
     if (p.C == 128) {      // 128 centroids per subspace (reference setup.py:15): streaming kernel by run-time layout flags only

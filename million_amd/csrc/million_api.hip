@@ -184,7 +184,8 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     if (p.k_paged || p.v_paged) {
         if (p.page_size != 32 && p.page_size != 64 && p.page_size != 128) { set_error("attn: page_size=%d (32, 64, 128)", p.page_size); return MILLION_ERR_SHAPE; }
         if ((long long)p.n_pages_cap * p.page_size < p.T) { set_error("attn: n_pages_cap*page_size < n_tokens"); return MILLION_ERR_ARG; }
-        if (p.n_pages_cap < 0 || (long long)p.bs * p.nh_k * p.n_pages_cap > 0x7fffffffLL) { set_error("attn: page table of %lld entries", (long long)p.bs * p.nh_k * p.n_pages_cap); return MILLION_ERR_ARG; }
+        // the kernels index the table with 32-bit arithmetic (int64 ids: two dwords per entry)
+        if (p.n_pages_cap < 0 || (long long)p.bs * p.nh_k * p.n_pages_cap > (p.ids64 ? 0x3fffffffLL : 0x7fffffffLL)) { set_error("attn: page table of %lld entries", (long long)p.bs * p.nh_k * p.n_pages_cap); return MILLION_ERR_ARG; }
     }
     p.dev_lengths = desc->dev_lengths;
     p.scale_log2e = 1.4426950408889634f / sqrtf((float)p.d);
@@ -394,8 +395,12 @@ int million_attn_kernel_kind(const million_attn_desc *desc) {
     AttnParams p;
     if (fill_attn_params(desc, p) != MILLION_OK) return -1;
     if (g_force_generic) return 0;
-    if (attn_mfma_supported(p)) return 1;
-    if (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) return 2;      // transpose + MFMA kernel
+    if (attn_mfma_supported(p) && attn_mfma_handles(p)) return 1;
+    if (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) {               // transpose + MFMA kernel
+        AttnParams pt = p;
+        pt.v_paged = 1; pt.v_identity = 1; pt.page_size = 64; pt.ps_shift = 6;
+        if (attn_mfma_handles(pt)) return 2;
+    }
     const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxG ? p.Gt : kMaxG);              // tile kernel: kMaxG heads per launch
     if (attn_tile_supported(p8)) return 3;                                            // tile kernel
     if (attn_tile_shape_ok(p8) && !p.v_paged && !p.k_paged) return 4;                 // transpose + tile kernel

@@ -224,16 +224,21 @@ class LlamaShapeDecoder:
         self.timers = NO_TIMERS
 
     def _rms(self, x, w):
-        v = x.float()
-        return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.s.eps)).half() * w
+        # one fused kernel (fp32 accumulation inside) instead of the eight of the spelled-out form: the decode step of this
+        # harness was ~60 small launches per layer, more GPU time than its weight GEMVs (rocprofv3, round 3)
+        return F.rms_norm(x, (x.shape[-1],), w, self.s.eps)
 
-    def _rope(self, x, pos):
-        # x (bs, heads, 1, d); HF rotate_half convention
+    def _rope_tables(self, pos):
+        """cos and sign-folded sin of one decode step (bs, 1, 1, d), computed once per step, not per layer and tensor."""
         ang = pos.float()[:, None] * self.inv_freq[None, :]            # (bs, d/2)
-        cos = torch.cat([ang.cos(), ang.cos()], -1)[:, None, None, :].half()
-        sin = torch.cat([ang.sin(), ang.sin()], -1)[:, None, None, :].half()
-        x1, x2 = x[..., : self.s.d // 2], x[..., self.s.d // 2:]
-        return x * cos + torch.cat([-x2, x1], -1) * sin
+        cos, sin = ang.cos(), ang.sin()
+        return (torch.cat([cos, cos], -1).half()[:, None, None, :], torch.cat([-sin, sin], -1).half()[:, None, None, :])
+
+    def _rope(self, x, tables):
+        # x (bs, heads, 1, d); HF rotate_half convention: rotate_half(x) = cat(-x2, x1) = roll(x, d/2) with the sign of the
+        # first half folded into the sin table
+        cos, sin_signed = tables
+        return torch.addcmul(x * cos, torch.roll(x, self.s.d // 2, -1), sin_signed)
 
     def _rope_seq(self, x, pos0):
         # x (bs, heads, n, d), positions pos0 .. pos0 + n - 1
@@ -250,22 +255,25 @@ class LlamaShapeDecoder:
         x = self.embed[tokens]                                           # (bs, hidden)
         if hasattr(backend, "begin_step"):
             backend.begin_step()
+        rope = self._rope_tables(pos)
         for l, L in enumerate(self.layers):
             hN = self._rms(x, L["n1"])
             with tm("qkv_proj"):
                 qkv = F.linear(hN, L["wqkv"])
-                q = qkv[:, : s.nh * s.d].view(bs, s.nh, 1, s.d)
-                k = qkv[:, s.nh * s.d: (s.nh + s.nh_k) * s.d].view(bs, s.nh_k, 1, s.d)
                 v = qkv[:, (s.nh + s.nh_k) * s.d:].view(bs, s.nh_k, 1, s.d)
             with tm("rotary"):
-                q, k = self._rope(q, pos).contiguous(), self._rope(k, pos).contiguous()
+                # q and k heads lie side by side in the fused projection: one rotary pass over both
+                qk = self._rope(qkv[:, : (s.nh + s.nh_k) * s.d].view(bs, s.nh + s.nh_k, 1, s.d), rope)
+                q, k = qk[:, : s.nh], qk[:, s.nh:]
+                if bs > 1:
+                    q, k = q.contiguous(), k.contiguous()
                 v = v.contiguous()
             a = backend.attend(l, q, k, v)
             with tm("o_proj"):
-                x = x + F.linear(a.reshape(bs, s.nh * s.d), L["wo"])
+                x = torch.addmm(x, a.reshape(bs, s.nh * s.d), L["wo"].t())      # residual add in the GEMV's epilogue
             hN = self._rms(x, L["n2"])
             gu = F.linear(hN, L["wgu"])
-            x = x + F.linear(F.silu(gu[:, : s.inter]) * gu[:, s.inter:], L["wd"])
+            x = torch.addmm(x, F.silu(gu[:, : s.inter]) * gu[:, s.inter:], L["wd"].t())
         self.last_logits = F.linear(self._rms(x, self.norm), self.lm_head)
         return self.last_logits.argmax(-1)
 

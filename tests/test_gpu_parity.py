@@ -1393,6 +1393,20 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
         _check(_run_paged(torch, ops, oracle, c, M, C, 64, k_paged=False, i64=True), gold, "tile mixed i64")
 
 
+def test_attn_kernel_kind_mirrors_the_hand_back(env, oracle):
+    """million_attn_kernel_kind answers what a call WOULD run: d = 128 / M = 64 / C = 128 is the streaming kernel's shape, but
+    with nothing quantised yet (T = 0) launch_attn_mfma hands the call to the tile kernel (kind 3), as it does for more
+    than 64 rounds per wave; C = 256 keeps the grouped MFMA kernel for those (kind 1)."""
+    torch, ops = env
+    c = synth.attn_case(7700, 1, 8, 2, 128, 64, 128, 0, 40, Lt=128)
+    t = _dev(torch, c)
+    kw = dict(nh_k=2, M=64, r=40, k_paged=True, v_paged=True, page_size=64)
+    assert _kind(torch, ops, t["q"], t["k_res"], C=128, n_tokens=0, n_pages_cap=1, **kw) == 3
+    assert _kind(torch, ops, t["q"], t["k_res"], C=128, n_tokens=4096, n_pages_cap=64, **kw) == 1
+    assert _kind(torch, ops, t["q"], t["k_res"], C=256, n_tokens=0, n_pages_cap=1, **kw) == 1
+    _check(_run_rowmajor(torch, ops, c, 64, 128), oracle.decode_attn(**c), "C=128 T=0 (tile kernel)")
+
+
 @pytest.mark.parametrize("d,M", [(64, 32), (128, 16), (64, 64)], ids=["d64M32", "d128M16", "d64M64"])
 @pytest.mark.parametrize("use_dl", [False, True], ids=["host-lengths", "device-lengths"])
 def test_attn_tile_kernel_ring_append_ragged(d, M, use_dl, env, oracle):
