@@ -240,14 +240,11 @@ class LlamaShapeDecoder:
         cos, sin_signed = tables
         return torch.addcmul(x * cos, torch.roll(x, self.s.d // 2, -1), sin_signed)
 
-    def _rope_seq(self, x, pos0):
-        # x (bs, heads, n, d), positions pos0 .. pos0 + n - 1
-        n = x.shape[2]
-        ang = (pos0 + torch.arange(n, device=x.device)).float()[:, None] * self.inv_freq[None, :]      # (n, d/2)
-        cos = torch.cat([ang.cos(), ang.cos()], -1)[None, None].half()
-        sin = torch.cat([ang.sin(), ang.sin()], -1)[None, None].half()
-        x1, x2 = x[..., : self.s.d // 2], x[..., self.s.d // 2:]
-        return x * cos + torch.cat([-x2, x1], -1) * sin
+    def _rope_seq_tables(self, n, pos0, device):
+        """cos / sign-folded sin of positions pos0 .. pos0 + n - 1, shaped (1, n, 1, d) for token-major (bs, n, heads, d)."""
+        ang = (pos0 + torch.arange(n, device=device)).float()[:, None] * self.inv_freq[None, :]      # (n, d/2)
+        cos, sin = ang.cos(), ang.sin()
+        return (torch.cat([cos, cos], -1).half()[None, :, None, :], torch.cat([-sin, sin], -1).half()[None, :, None, :])
 
     def step(self, tokens, pos, backend):
         s, tm = self.s, self.timers
@@ -284,23 +281,27 @@ class LlamaShapeDecoder:
         s, tm = self.s, self.timers
         bs, n = tokens.shape
         x = self.embed[tokens]                                           # (bs, n, hidden)
+        rope = self._rope_seq_tables(n, 0, x.device)
         for l, L in enumerate(self.layers):
             hN = self._rms(x, L["n1"])
             with tm("qkv_proj"):
                 qkv = F.linear(hN, L["wqkv"])
-                q = qkv[..., : s.nh * s.d].view(bs, n, s.nh, s.d).transpose(1, 2)
-                k = qkv[..., s.nh * s.d: (s.nh + s.nh_k) * s.d].view(bs, n, s.nh_k, s.d).transpose(1, 2)
-                v = qkv[..., (s.nh + s.nh_k) * s.d:].view(bs, n, s.nh_k, s.d).transpose(1, 2).contiguous()
             with tm("rotary"):
-                q, k = self._rope_seq(q, 0).contiguous(), self._rope_seq(k, 0).contiguous()
+                # token-major all the way: one rotary pass over the q and k heads where the projection left them; the
+                # (bs, heads, n, d) tensors handed to the backend are strided views (the attention and encode kernels of
+                # this library take row strides; torch's SDPA and cat do too)
+                qk = self._rope(qkv[..., : (s.nh + s.nh_k) * s.d].view(bs, n, s.nh + s.nh_k, s.d), rope)
+                q, k = qk[:, :, : s.nh].transpose(1, 2), qk[:, :, s.nh:].transpose(1, 2)
+                v = qkv[..., (s.nh + s.nh_k) * s.d:].view(bs, n, s.nh_k, s.d).transpose(1, 2)
             a = backend.prefill(l, q, k, v)                              # (bs, nh, n, d)
             with tm("o_proj"):
-                x = x + F.linear(a.transpose(1, 2).reshape(bs, n, s.nh * s.d), L["wo"])
-            del qkv, q, k, v, a
+                x.view(bs * n, s.hidden).addmm_(a.transpose(1, 2).reshape(bs * n, s.nh * s.d), L["wo"].t())
+            del qkv, qk, q, k, v, a
             for c0 in range(0, n, chunk):
-                hN = self._rms(x[:, c0:c0 + chunk], L["n2"])
+                xc = x[:, c0:c0 + chunk]
+                hN = self._rms(xc, L["n2"])
                 gu = F.linear(hN, L["wgu"])
-                x[:, c0:c0 + chunk] += F.linear(F.silu(gu[..., : s.inter]) * gu[..., s.inter:], L["wd"])
+                xc += F.linear(F.silu(gu[..., : s.inter]) * gu[..., s.inter:], L["wd"])
         self.last_logits = F.linear(self._rms(x[:, -1], self.norm), self.lm_head)
         return self.last_logits.argmax(-1)
 

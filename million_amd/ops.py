@@ -404,7 +404,9 @@ def prefill_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: b
     fix = lambda t: t if (t.stride(3) == 1 and all(s_ % 8 == 0 for s_ in t.stride()[:3])) else t.contiguous()
     q, k, v = fix(q), fix(k), fix(v)
     if out is None:
-        out = torch.empty(bs, nh, n_q, d, dtype=torch.float16, device=q.device)
+        # token-major memory under the (bs, nh, n_q, d) shape: the o_proj of a prompt pass wants (bs, n, nh * d), and
+        # out.transpose(1, 2).reshape(bs, n, nh * d) is then a view instead of a copy of the whole output
+        out = torch.empty(bs, n_q, nh, d, dtype=torch.float16, device=q.device).transpose(1, 2)
     elif out.shape != (bs, nh, n_q, d) or out.dtype != torch.float16 or out.stride(3) != 1:
         raise RuntimeError("prefill_attn: out must be fp16 (bs, nh, n_q, d) with contiguous rows")
     desc = L.PrefillDesc()
