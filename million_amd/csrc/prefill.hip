@@ -26,7 +26,13 @@
 // Roofline: MFMA (2.5 PFLOP/s dense fp16).  FLOPs = 4 d nh (number of unmasked (i, j) pairs).  Per 64-key tile a wave
 // issues 32 MFMAs (32 cycles each) and reads 32 KiB of LDS (K and V^T fragments are re-read by each of the 8 waves: 256
 // B/clk/CU at the MFMA rate, i.e. the LDS ceiling equals the MFMA ceiling in this 8 x 32-row decomposition).
+#include <type_traits>
+
 #include "common.h"
+
+#ifndef MILLION_EXP
+#define MILLION_EXP 0      // development ablation switches (tools/ab_build.py, tools/pf_ab.sh); 0 in the product build:
+#endif                     // 1 no exponentials, 2 no barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
 
 namespace million {
 
@@ -146,23 +152,34 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
         store_tile(0);
     }
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
+    // One key tile.  The buffer index is a compile-time constant (the tile loop below is unrolled by two) and the reads are
+    // written as lane pointer + constant element index: the buffer's base then rides in the immediate offset of every
+    // ds_read instead of one v_or per read (48 per tile; written as integer arithmetic hipcc hoisted a second set of 48
+    // address registers instead and spilled).
+    auto tile = [&](auto bufc, const int t) {
+        constexpr int buf = decltype(bufc)::value;
+#if !(MILLION_EXP & 16)
         load_tile(t + 1 < nt ? t + 1 : t);      // next tile's bytes fly during this tile's products (the last one re-reads itself)
+#endif
         const int kv0 = t * kKV;
         const bool tile_live = wave_live && (!p.causal || kv0 <= w_pos_hi);      // wave-uniform
         if (tile_live) {
-            const unsigned kb = 2u * kTileBytes * buf, vb = kb + kTileBytes;
+            constexpr unsigned kb = 2u * kTileBytes * buf, vb = kb + kTileBytes;
             // ---- S^T = K Q^T: two 32-key x 32-query tiles ----
             v16f S0, S1;
 #pragma unroll
             for (int j = 0; j < 16; ++j) { S0[j] = 0.f; S1[j] = 0.f; }
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
-                const v8h a0 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off<D>(r32, 2 * s + hh)));
-                const v8h a1 = __builtin_bit_cast(v8h, *(lds_v4u_p)(size_t)(kb + pf_off<D>(32 + r32, 2 * s + hh)));
+                const v8h a0 = __builtin_bit_cast(v8h, ((lds_v4u_p)(size_t)pf_off<D>(r32, 2 * s + hh))[kb / 16]);
+                const v8h a1 = __builtin_bit_cast(v8h, ((lds_v4u_p)(size_t)pf_off<D>(32 + r32, 2 * s + hh))[kb / 16]);
+#if MILLION_EXP & 8
+                S0[s] += (float)a0[0] * (float)qf[s][0];
+                S1[s] += (float)a1[0] * (float)qf[s][0];
+#else
                 S0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[s], S0, 0, 0, 0);
                 S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[s], S1, 0, 0, 0);
+#endif
             }
             // ---- mask (only where the diagonal or the end of the keys crosses this tile), scale, online softmax ----
             float sc[32];
@@ -199,7 +216,11 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
             float ls = 0.f;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
+#if MILLION_EXP & 1
+                sc[j] = fmaf(sc[j], c, -m_safe);
+#else
                 sc[j] = __builtin_amdgcn_exp2f(fmaf(sc[j], c, -m_safe));
+#endif
                 ls += sc[j];
             }
             l_run += ls;
@@ -223,17 +244,29 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
 #pragma unroll
                     for (int blk = 0; blk < NB; ++blk) {
                         const int chn = 4 * blk + 2 * g16 + (pp >> 1);
-                        const pv4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off<D>(kvr0 + qd, chn) + 8 * (pp & 1)));
-                        const pv4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(vb + pf_off<D>(kvr0 + 8 + qd, chn) + 8 * (pp & 1)));
+                        const pv4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(pf_off<D>(kvr0 + qd, chn) + 8 * (pp & 1)) + vb / 8);
+                        const pv4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)(pf_off<D>(kvr0 + 8 + qd, chn) + 8 * (pp & 1)) + vb / 8);
                         typedef short v8s __attribute__((ext_vector_type(8)));
                         const v8s av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#if MILLION_EXP & 4
+                        O[blk][0] += (float)av[0] * (float)pb[0];
+#else
                         O[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, av), pb, O[blk], 0, 0, 0);
+#endif
                     }
                 }
         }
         // the other buffer was last read in iteration t - 1; every wave has passed that iteration's barrier
+#if !(MILLION_EXP & 16)
         if (t + 1 < nt) store_tile(buf ^ 1);
+#endif
+#if !(MILLION_EXP & 2)
         __syncthreads();
+#endif
+    };
+    for (int t = 0; t < nt; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1);
     }
     // ---- normalise and store: lane (q, h) holds dims 32 blk + 8 i + 4 h + (0..3) of its row ----
     {
