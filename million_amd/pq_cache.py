@@ -789,7 +789,8 @@ class PagedPQCache(_CacheBase):
             self._pre_a[full] = 0
         elif kind.startswith("pre"):
             g0, g1 = self._ea_groups()[int(kind[3:] or 0)]
-            self._pre_a[g0:g1] = 1
+            if not (self.preallocate and int(self._T_a[0, 0]) + ps > self.max_tokens):      # begin_step encoded nothing then
+                self._pre_a[g0:g1] = 1
         self._r_a += 1
         self._seen_a += 1
 
