@@ -76,7 +76,6 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     constexpr int NB = D / 32;                 // 32-row blocks of O^T
     constexpr int CPR = D / 8;                 // 16-byte chunks per row
     constexpr int kTileBytes = kKV * 2 * D;    // one [64][D] fp16 tile
-    constexpr int NCH = kKV * CPR / (kPW * 64);      // chunks of a tile per thread (2 / 1)
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];      // [2 buffers][K tile | V tile]
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_smem != 0u) __builtin_trap();      // absolute LDS addressing below
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,29 +114,43 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     const int w_pos_lo = p.q_pos0 + q_lo, w_pos_hi = p.q_pos0 + q_lo + 31;                // positions of this wave's rows
     const bool wave_live = q_lo < p.n_q;                                                   // wave-uniform
 
-    // ---- staging: thread -> two 16-byte chunks of the K tile and two of the V tile ----
+    // ---- staging: global -> LDS directly (global_load_lds_dwordx4: no registers, no ds_write).  A wave instruction moves
+    //      64 x 16 bytes into 1 KiB of CONSECUTIVE LDS, so the swizzle of the image is applied on the global side: lane l of
+    //      piece j fills 16-byte slot 64 j + l of a tile and fetches the (row, chunk) that pf_off puts there.  The ablation
+    //      of the register-staged form priced staging at 1.3 of 9.2 ms (address arithmetic, 4 global loads + 4 ds_write_b128
+    //      per thread and tile, the wait in front of the stores).  The instruction is issued from inline asm: hipcc answers the
+    //      builtin with s_waitcnt vmcnt(0) in front of every later LDS read; the waits are explicit (dma_wait) instead. ----
     const f16 *kbase = p.k + b * p.k_sb + hk * p.k_sh;
     const f16 *vbase = p.v + b * p.v_sb + hk * p.v_sh;
-    pv4u kreg[NCH], vreg[NCH];
-    auto load_tile = [&](int t) {
+    constexpr int kPieces = kTileBytes / 1024;          // 1-KiB pieces per tile side (16 / 8)
+    constexpr int NPW = 2 * kPieces / kPW;              // pieces per wave and tile: K and V (4 / 2)
+    int prow[NPW], pch[NPW];                            // the (row, 16-byte chunk) this lane fetches for its piece i
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 512 * i, row = c / CPR, ch = c % CPR;
-            int kvr = t * kKV + row;
+    for (int i = 0; i < NPW; ++i) {
+        const int pc = (wave + kPW * i) % kPieces;      // piece within its side
+        const int pos = 64 * pc + lane;                 // 16-byte slot of the tile image
+        if (D == 128) {
+            prow[i] = pos >> 4;
+            pch[i] = (pos & 15) ^ (((prow[i] & 3) << 2) | ((prow[i] >> 2) & 3));
+        } else {
+            const int rp = pos >> 4, x = (pos & 15) ^ (((rp & 1) << 2) | ((rp >> 2) & 3));
+            prow[i] = 2 * rp + (x >> 3);
+            pch[i] = x & 7;
+        }
+    }
+    auto dma_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pcg = wave + kPW * i;             // wave-uniform: pieces [0, kPieces) are K, the rest V
+            const bool is_v = pcg >= kPieces;
+            int kvr = t * kKV + prow[i];
             kvr = kvr < p.n_kv ? kvr : p.n_kv - 1;      // clamped: rows past the end are masked below
-            kreg[i] = *(const pv4u *)(kbase + (long long)kvr * p.k_sn + 8 * ch);
-            vreg[i] = *(const pv4u *)(vbase + (long long)kvr * p.v_sn + 8 * ch);
+            const f16 *src = (is_v ? vbase + (long long)kvr * p.v_sn : kbase + (long long)kvr * p.k_sn) + 8 * pch[i];
+            const unsigned dst = 2u * kTileBytes * buf + (is_v ? kTileBytes : 0) + 1024u * (pcg % kPieces);
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");      // (nothing else in this kernel uses M0: checked in the ISA)
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 512 * i, row = c / CPR, ch = c % CPR;
-            const unsigned o = 2u * kTileBytes * buf + pf_off<D>(row, ch);
-            *(lds_v4u_p)(size_t)o = kreg[i];
-            *(lds_v4u_p)(size_t)(o + kTileBytes) = vreg[i];
-        }
-    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     v16f O[NB];
 #pragma unroll
@@ -147,10 +160,8 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     float m_run = -INFINITY, l_run = 0.f;      // m in the scaled exp2 domain
     const float c = p.scale_log2e;
 
-    if (nt > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
+    if (nt > 0) dma_tile(0, 0);
+    dma_wait();
     __syncthreads();
     // One key tile.  The buffer index is a compile-time constant (the tile loop below is unrolled by two) and the reads are
     // written as lane pointer + constant element index: the buffer's base then rides in the immediate offset of every
@@ -159,7 +170,9 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     auto tile = [&](auto bufc, const int t) {
         constexpr int buf = decltype(bufc)::value;
 #if !(MILLION_EXP & 16)
-        load_tile(t + 1 < nt ? t + 1 : t);      // next tile's bytes fly during this tile's products (the last one re-reads itself)
+        // the other buffer was last read in iteration t - 1 and every wave has passed that iteration's barrier: the next
+        // tile's bytes fly into it during this tile's products
+        if (t + 1 < nt) dma_tile(t + 1, buf ^ 1);
 #endif
         const int kv0 = t * kKV;
         const bool tile_live = wave_live && (!p.causal || kv0 <= w_pos_hi);      // wave-uniform
@@ -256,10 +269,7 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
                     }
                 }
         }
-        // the other buffer was last read in iteration t - 1; every wave has passed that iteration's barrier
-#if !(MILLION_EXP & 16)
-        if (t + 1 < nt) store_tile(buf ^ 1);
-#endif
+        dma_wait();
 #if !(MILLION_EXP & 2)
         __syncthreads();
 #endif
