@@ -26,6 +26,7 @@
 // Roofline: MFMA (2.5 PFLOP/s dense fp16).  FLOPs = 4 d nh (number of unmasked (i, j) pairs).  Per 64-key tile a wave
 // issues 32 MFMAs (32 cycles each) and reads 32 KiB of LDS (K and V^T fragments are re-read by each of the 8 waves: 256
 // B/clk/CU at the MFMA rate, i.e. the LDS ceiling equals the MFMA ceiling in this 8 x 32-row decomposition).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -52,7 +53,7 @@ struct PrefillParams {
     float scale_log2e;
 };
 
-constexpr int kPW = 8;            // waves
+constexpr int kPWDefault = 8;     // waves per workgroup (template parameter kPW of the kernel)
 constexpr int kKV = 64;           // keys per tile
 
 // LDS image of a [64 keys][D] fp16 tile; off(row, ch) = byte offset of 16-byte chunk ch of a row.  D = 128 (256-byte rows):
@@ -70,11 +71,10 @@ typedef __attribute__((address_space(3))) pv4u *lds_v4u_p;
 typedef __attribute__((address_space(3))) pv4s *lds_v4s_p;
 
 // D = 128 (the Llama head size of every BASELINE config) and D = 64 (the other head size the reference builds, setup.py:12).
-template <int D>
+template <int D, int kPW>
 __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams p) {
     constexpr int DS = D / 16;                 // k-steps of the score product
     constexpr int NB = D / 32;                 // 32-row blocks of O^T
-    constexpr int CPR = D / 8;                 // 16-byte chunks per row
     constexpr int kTileBytes = kKV * 2 * D;    // one [64][D] fp16 tile
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];      // [2 buffers][K tile | V tile]
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_smem != 0u) __builtin_trap();      // absolute LDS addressing below
@@ -299,24 +299,28 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     }
 }
 
+template <int D, int PW>
+static void launch_prefill_t(const PrefillParams &p, long long blocks, int lds, hipStream_t s) {
+    static bool once = false;      // (per process; the attribute is per function, devices share the code object)
+    if (!once) { (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<D, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * D); once = true; }
+    hipLaunchKernelGGL((prefill_attn_kernel<D, PW>), dim3((unsigned)blocks), dim3(PW * 64), lds, s, p);
+}
+
 int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
     PrefillParams p = p_in;
+    static const int pw = [] { const char *e = getenv("MILLION_PREFILL_WAVES"); return e && e[0] == '4' ? 4 : kPWDefault; }();      // development A/B
     int hpw = 1;
     for (int c = 8; c >= 1; c >>= 1)
-        if (p.G % c == 0) { hpw = c; break; }
+        if (p.G % c == 0 && c <= pw) { hpw = c; break; }
     p.hpw = hpw;
-    const int QB = (kPW / hpw) * 32;
+    const int QB = (pw / hpw) * 32;
     p.n_qb = (p.n_q + QB - 1) / QB;
     const long long blocks = (long long)p.bs * p.nh_k * (p.G / hpw) * p.n_qb;
     if (blocks <= 0) return MILLION_OK;
     if (blocks > 0x7fffffffLL) { set_error("prefill: %lld workgroups", blocks); return MILLION_ERR_SHAPE; }
     const int lds = 4 * kKV * 2 * p.d;      // two buffers of (K tile, V tile)
-    if (device_once(3)) {
-        (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 256);
-        (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 128);
-    }
-    if (p.d == 128) hipLaunchKernelGGL(prefill_attn_kernel<128>, dim3((unsigned)blocks), dim3(kPW * 64), lds, s, p);
-    else hipLaunchKernelGGL(prefill_attn_kernel<64>, dim3((unsigned)blocks), dim3(kPW * 64), lds, s, p);
+    if (p.d == 128) { if (pw == 4) launch_prefill_t<128, 4>(p, blocks, lds, s); else launch_prefill_t<128, 8>(p, blocks, lds, s); }
+    else { if (pw == 4) launch_prefill_t<64, 4>(p, blocks, lds, s); else launch_prefill_t<64, 8>(p, blocks, lds, s); }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("prefill launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }
     return MILLION_OK;
