@@ -1644,6 +1644,100 @@ def test_debug_build_bounds_checks_page_ids(env):
         assert c["bad_ids"] >= 3 and c["finite"] and c["other_head_err"] < 1e-3 and c["hurt_head_moved"], c
 
 
+# ---------------------------------------------------------------- size-independent properties at the BASELINE sizes --------
+_BASELINE_SHAPES = [("configs2", 1, 32, 8, 64, 32768 + 64), ("configs3-per-gpu", 2, 32, 8, 64, 32768 + 64),
+                    ("configs4", 1, 32, 8, 32, 131072), ("configs1", 1, 32, 32, 64, 4096)]
+
+
+@pytest.mark.parametrize("name,bs,nh,nhk,M,T", _BASELINE_SHAPES, ids=[c[0] for c in _BASELINE_SHAPES])
+def test_attn_properties_at_baseline_sizes(name, bs, nh, nhk, M, T, env):
+    """No oracle at these sizes beyond the sampled comparisons elsewhere: properties of the operator itself, on the fused
+    paged launch at every BASELINE.json shape.
+    (1) the physical order of the pages does not matter: a shuffled pool + matching ids gives the SAME BITS (the kernel reads
+        the same codes in the same order);
+    (2) requests are independent: request 0 alone gives what it gives inside the batch (batch shapes; to rounding: it is cut
+        into other splits), and two query heads fed the same q row give the same output row, bit for bit;
+    (3) the output is linear in the value codebook: 2 x v_cents doubles it;
+    (4) it is a convex combination: every output coordinate lies inside the range of the centroid / window values of its dim."""
+    torch, ops = env
+    d, C, ps, r = 128, 256, 64, 100
+    g = torch.Generator(device="cuda").manual_seed(1234 + T + M + bs)
+    n_pages = T // ps
+    G = nh // nhk
+    q = torch.randn(bs, nh, 1, d, device="cuda", generator=g).half()
+    q[:, 1] = q[:, 0]                                               # (2) two heads of kv head 0 with the same query
+    kc = torch.randn(M, C, d // M, device="cuda", generator=g).half()
+    vc = torch.randn(M, C, d // M, device="cuda", generator=g).half()
+    kres = torch.randn(bs, nhk, 128, d, device="cuda", generator=g).half()
+    vres = torch.randn(bs, nhk, 128, d, device="cuda", generator=g).half()
+    n_pool = bs * nhk * n_pages
+    kpool = torch.randint(0, C, (n_pool, ps, M), device="cuda", generator=g, dtype=torch.uint8)
+    vpool = torch.randint(0, C, (n_pool, M, ps), device="cuda", generator=g, dtype=torch.uint8)
+    ids = torch.arange(n_pool, device="cuda", dtype=torch.int32).view(bs, nhk, n_pages)
+    kp, vp = ops.prepare_cents(kc, cache=False), ops.prepare_cents(vc, cache=False)
+
+    def run(kpool_, vpool_, ids_, vp_=vp, sel=slice(None)):
+        out = ops.pq_decode_attn(q[sel].contiguous(), kpool_, vpool_, kp, vp_, kres[sel].contiguous(), vres[sel].contiguous(), r,
+                                 M=M, C=C, n_tokens=T, k_page_ids=ids_[sel].contiguous(), v_page_ids=ids_[sel].contiguous(), page_size=ps)
+        torch.cuda.synchronize()
+        return out
+
+    base = run(kpool, vpool, ids)
+    assert torch.isfinite(base.float()).all()
+    # (1) page order
+    perm = torch.randperm(n_pool, device="cuda", generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n_pool, device="cuda")
+    assert torch.equal(run(kpool[perm], vpool[perm], inv[ids.long()].int()), base)
+    # (2) independence of requests and of heads
+    if bs > 1:
+        # (alone the request is cut into twice as many splits: another summation order, not another result)
+        assert torch.allclose(run(kpool, vpool, ids, sel=slice(0, 1)).float(), base[0:1].float(), rtol=2e-3, atol=2e-4)
+    if G > 1:
+        assert torch.equal(base[:, 0], base[:, 1])
+    # (3) linearity in the value codebook (the window's V rows are scaled with it)
+    vres2 = vres * 2
+    out2 = ops.pq_decode_attn(q, kpool, vpool, kp, ops.prepare_cents(vc * 2, cache=False), kres, vres2, r, M=M, C=C, n_tokens=T,
+                              k_page_ids=ids, v_page_ids=ids, page_size=ps)
+    torch.cuda.synchronize()
+    # (not bit for bit: fp16 denormals among the centroids are flushed by the MFMA, their doubles are not)
+    assert torch.allclose(out2.float(), base.float() * 2, rtol=2e-3, atol=2e-4)
+    # (4) convexity: per output dim, within [min, max] of what a token can contribute there (centroid table / window rows)
+    dm = d // M
+    lo = torch.minimum(vc.float().amin(1).reshape(d), vres[:, :, :r].float().amin((0, 1, 2)))
+    hi = torch.maximum(vc.float().amax(1).reshape(d), vres[:, :, :r].float().amax((0, 1, 2)))
+    o = base.float().reshape(-1, d)
+    assert (o >= lo - 1e-2).all() and (o <= hi + 1e-2).all()
+    assert dm in (2, 4)
+
+
+def test_encode_properties_at_baseline_size(env):
+    """PQ encode at the 32K-token prompt size of configs[2] (8 kv heads): idempotence - a decoded row encodes to a code that
+    decodes to the same row (the nearest centroid of a centroid is itself) - and layout independence: the codes
+    that land in K pages / transposed V pages are the row-major codes, byte for byte."""
+    torch, ops = env
+    bs, nhk, n, d, M, C, ps = 1, 8, 32768, 128, 64, 256, 64
+    g = torch.Generator(device="cuda").manual_seed(77)
+    X = torch.randn(bs, nhk, n, d, device="cuda", generator=g).half()
+    cents = torch.randn(M, C, d // M, device="cuda", generator=g).half()
+    codes = ops.pq_encode(X, cents)
+    dec = ops.pq_decode(codes, cents)
+    again = ops.pq_encode(dec, cents)
+    assert torch.equal(ops.pq_decode(again, cents), dec)          # (codes may differ only where two centroids are the same fp16 pair)
+    assert (again != codes).sum().item() <= codes.numel() // 10000
+    n_pages = n // ps
+    ids = torch.randperm(bs * nhk * n_pages, device="cuda", generator=g).int().view(bs, nhk, n_pages)
+    kpool = torch.zeros(bs * nhk * n_pages, ps, M, dtype=torch.uint8, device="cuda")
+    vpool = torch.zeros(bs * nhk * n_pages, M, ps, dtype=torch.uint8, device="cuda")
+    from million_amd import _lib as L
+    ops.pq_encode_into(X, cents, kpool, layout=L.MILLION_CODES_KPAGES, page_ids=ids, page_size=ps, n=n, token_start=0)
+    ops.pq_encode_into(X, cents, vpool, layout=L.MILLION_CODES_VPAGES, page_ids=ids, page_size=ps, n=n, token_start=0)
+    torch.cuda.synchronize()
+    want = codes.view(bs, nhk, n_pages, ps, M)
+    assert torch.equal(kpool[ids.long()], want)
+    assert torch.equal(vpool[ids.long()].transpose(-1, -2), want)
+
+
 # ---------------------------------------------------------------- prompt (prefill) attention on fp16 K/V -------------------
 def _sdpa_ref_rows(q, k, v, rows, q_pos0=0, causal=True):
     """fp64 reference of selected query rows: q (bs, nh, n_q, d), k / v (bs, nh_k, n_kv, d) numpy -> (bs, nh, len(rows), d)."""
