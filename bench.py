@@ -556,7 +556,33 @@ def cpu_baseline(bs, nh, nhk, d, M, C, T, r, layers):
     per_layer = (time.perf_counter() - t0) / reps
     return {"value": round(bs / (per_layer * layers), 4), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x one layer-call (T={T}, fp32 torch-CPU restatement of sa_decode_4d + cat + SDPA) "
-                      f"= {per_layer * 1e3:.1f} ms, scaled x{layers} layers"}
+                      f"= {per_layer * 1e3:.1f} ms, scaled x{layers} layers",
+            "encode": cpu_baseline_encode(bs, nhk, d, M, C, cores)}
+
+
+def cpu_baseline_encode(bs, nhk, d, M, C, cores):
+    """the encode leg on the host's cores - the reference's CPU-runnable sa_encode_4d (torch.cdist + argmin,
+    pq_utils.py:410-449; oracle.pq_encode_cdist_torch) and the direct form of its GPU encoder (pq_utils.py:483-494;
+    oracle.pq_encode_direct_torch), fp32, on (i) one layer's flush page (page_size 64 rows x nh_k heads x requests, K and V
+    sides) and (ii) a 4096-token prompt slice of one request (K and V sides).  Bounded: <= ~4 s per cell."""
+    import torch
+    from oracle import oracle as O
+    g = torch.Generator().manual_seed(11)
+    cents = torch.randn(M, C, d // M, generator=g).half().float().numpy()
+    out = {"unit": "ms per layer, K and V sides", "cores": cores, "dtype": "f32"}
+    for name, n, nb in (("flush_page_64_rows", 64, bs), ("prompt_4096_tokens", 4096, 1)):
+        X = torch.randn(nb, nhk, n, d, generator=g).half().float().numpy()
+        cell = {}
+        for form, fn in (("cdist", O.pq_encode_cdist_torch), ("direct", O.pq_encode_direct_torch)):
+            fn(X[:, :, :min(n, 64)], cents)      # warm-up
+            t0, reps = time.perf_counter(), 0
+            while reps < 1 or (time.perf_counter() - t0 < 2.0 and reps < 20):
+                fn(X, cents)
+                reps += 1
+            cell[form] = round(2.0 * (time.perf_counter() - t0) / reps * 1e3, 3)      # x 2: K side and V side
+        out[name] = cell
+    out["rows_per_s_direct_prompt"] = round(2 * nhk * 4096 / (out["prompt_4096_tokens"]["direct"] * 1e-3), 1)
+    return out
 
 
 if __name__ == "__main__":

@@ -281,6 +281,11 @@ int million_lengths_advance(int32_t *dev_lengths, int bs, int n_flushed, int res
  * returns (and clears) the number of page ids outside [0, k_pool_pages) / [0, v_pool_pages) that the three decode-attention
  * kernels have met since the last call; such ids were read as page 0 instead of as out-of-bounds addresses. */
 int million_debug_bad_page_ids(void);
+/* Diagnostics: waits for the device and returns (and clears) the number of (b, kv head) merges of the MFMA decode-attention
+ * kernels that gave up waiting for a split's partial (a workgroup of the launch died, or the workspace was not zeroed).  The
+ * heads concerned were written as NaN.  0 in every healthy run; after a non-zero answer zero the workspace again
+ * (million_workspace_init).  -1: the runtime refused the read. */
+int million_debug_tail_faults(void);
 /* Diagnostics only: when `buf` is non-NULL the decode-attention kernels store up to 16 x uint64 realtime-counter
  * stamps (100 MHz) per wave at their phase boundaries into buf (grid_size * 8 waves * 32 slots entries).  NULL = off. */
 void million_debug_set_stamp_buffer(void *buf);

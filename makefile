@@ -5,6 +5,12 @@ PYTHON ?= python3
 bindings:
 	$(PYTHON) -m million_amd.build
 
+install: bindings   # reference makefile:1-4 installs the module; here: a .pth file in the user site-packages (what `pip install -e .` does)
+	$(PYTHON) tools/install_pth.py
+
+uninstall:
+	$(PYTHON) tools/install_pth.py --uninstall
+
 debug-ids:         # diagnostic variant: page ids bounds-checked in the decode-attention kernels (MILLION_HIP_LIB=million_amd/libmillion_hip_dbgids.so)
 	$(PYTHON) -m million_amd.build --debug-ids
 
@@ -26,4 +32,4 @@ bench:
 clean:
 	rm -f million_amd/libmillion_hip.so million_amd/libmillion_hip_dbgids.so oracle/libpq_oracle.so
 
-.PHONY: bindings debug-ids oracle golden test test-gpu bench clean
+.PHONY: bindings install uninstall debug-ids oracle golden test test-gpu bench clean

@@ -70,6 +70,7 @@ SYMBOLS = {
     "million_set_force_generic": (None, [c_i32]),
     "million_debug_set_stamp_buffer": (None, [c_vp]),
     "million_debug_bad_page_ids": (c_i32, []),
+    "million_debug_tail_faults": (c_i32, []),
     "million_debug_rows_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "million_lengths_advance": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "million_residual_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64,

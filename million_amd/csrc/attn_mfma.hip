@@ -557,12 +557,14 @@ __device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&p
 //     write-through 4-byte store), and at the start of its tail it reads the line: only if all nsplit slots carry its own
 //     XCC id does it store its partial plain; otherwise (another XCD, or a workgroup that has not started yet)
 //     write-through (sc1), which any XCD can read.  Loads and polls are sc1 in both cases;
-//   * nobody waits for a ticket: the arrival index is taken at the START of the tail (wave 7, which stores nothing; the
-//     round trip hides behind the wave merge); the storing waves drain their stores, and behind the workgroup barrier
-//     they then join the split's FLAG (= generation + 1) is raised; the nm = min(G, nsplit) workgroups whose index is highest are the
-//     mergers: four waves of each poll the flags (lane = split, bounded) and merge ONE query head - 16 KiB of loads, wave
-//     reductions by DPP / row swaps, no LDS, no barrier.  Every workgroup a merger waits for has reached its own tail and
-//     waits for nothing, so the polls end under any dispatch order;
+//   * nobody waits for a ticket: the arrival index is requested ~3 us ahead of the tail (wave 7, which stores nothing);
+//     the storing waves drain their stores, and behind the workgroup barrier they then join the split's FLAG (= generation
+//     + 1) is raised; the workgroup whose index is ns - 1 is the merger (round 4: the only one): its waves poll the flags
+//     (lane = split, bounded) and merge the query heads, four waves per head and two heads per pass - 16 KiB of loads per
+//     head, wave reductions by DPP / row swaps, no LDS, no barrier.  Every workgroup it waits for has taken its index, so
+//     it is resident, past its loop and waits for nothing: the polls end under any dispatch order and any residency.  A
+//     poll that runs out of its bound is COUNTED (g_tail_faults, million_debug_tail_faults) and the heads are written as
+//     NaN, never as the sum of stale partials;
 //   * the workgroup with the highest index clears the census line and the counter and advances the generation once its
 //     own poll has seen every flag (all census reads and stores of the launch are behind those flags);
 //   * nsplit = 1: the only workgroup normalises and writes the output itself.
@@ -624,53 +626,69 @@ __device__ __forceinline__ float wave_sum_valu(float x) {
     return rows_sum(x);
 }
 
+// Count of merges that gave up waiting for a split's flag (million_debug_tail_faults): never non-zero unless a workgroup of the
+// launch died or the workspace was not zeroed; the heads concerned are written as NaN, never as a stale partial's sum.
+__device__ unsigned g_tail_faults = 0;
+
 // One query head is merged by FOUR waves: wave part (0..3) owns outputs [32 part, 32 part + 32) of the head; its lane
-// (h, q8) owns float4 q8 of those for the splits s = h (mod 8): ns / 8 16-byte loads per lane (one wave per head: 16 per
-// lane and 1.2 us from "every flag seen" to "output written"), the eight split subsets are summed with DPP / row swaps.
-__device__ __forceinline__ void tail_merge_head_part(const AttnParams &p, int b, int hk, int g, int part, int ns, const float *src,
-                                                     int lane) {
+// (h, q8) owns float4 q8 of those for the splits s = h (mod 8): ns / 8 16-byte loads per lane, the eight split subsets are
+// summed with DPP / row swaps.  NJ = 2 merges heads g and g + 2 in one pass: every load of both heads is issued before the
+// first reduction (one memory round trip for the pair; round 4: the ONE merging workgroup serves all heads, see
+// merge_and_publish).  `second` is wave-uniform: false = only head g.
+template <int NJ>
+__device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int hk, int g, int part, int ns, const float *src,
+                                                 int lane, bool second, bool fault) {
     const int q8 = lane & 7, h = lane >> 3;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
     // softmax weights of the splits (lane = split)
     const bool on = lane < ns;
     const int sl = on ? lane : 0;
-    const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + g) * 4, 0, 16));
-    const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + g) * 4, 0, 16));
-    v4u v[8];
+    float m1[NJ], l1[NJ];
+    v4u v[NJ][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int slot = 8 * k + h;
-        const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
-        if (k < 4 || ns > 32)                                          // wave-uniform: the second half only for more than 32 splits
-            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * 128 + 32 * part + 4 * q8) * 4, 0, 16);
-        else
-            v[k] = v4u{0, 0, 0, 0};
-    }
-    const float m0 = on ? m1 : -INFINITY;
-    const float l0 = on ? l1 : 0.f;
-    const float mx = wave_max_valu(m0);
-    const float ms_ = mx > -INFINITY ? mx : 0.f;
-    const float w0 = fast_exp2(m0 - ms_);                               // -inf -> 0 (lanes >= ns: 0)
-    // unnormalised sum first, 1 / (sum of w l) at the end: the denominator's reduction runs beside the accumulation
-    v4f32 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int gj = (jj == 0 || second) ? g + 2 * jj : g;      // a missing second head re-reads the first (never a conditional load)
+        m1[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + gj) * 4, 0, 16));
+        l1[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + gj) * 4, 0, 16));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (8 * k + h), __builtin_bit_cast(int, w0)));
-        acc += w * __builtin_bit_cast(v4f32, v[k]);
+        for (int k = 0; k < 8; ++k) {
+            const int slot = 8 * k + h;
+            const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
+            if (k < 4 || ns > 32)                                          // wave-uniform: the second half only for more than 32 splits
+                v[jj][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + gj * 128 + 32 * part + 4 * q8) * 4, 0, 16);
+            else
+                v[jj][k] = v4u{0, 0, 0, 0};
+        }
     }
-    const float den = wave_sum_valu(w0 * l0);
-    const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;    // nothing to attend to: 0
-    // sum over the eight split subsets: lanes l, l ^ 8 (same 16-lane row), then the four rows
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float x = acc[c];
-        x += MILLION_DPP(x, 0x128);      // row_ror:8
-        acc[c] = rows_sum(x) * inv;
-    }
-    if (lane < 8) {
-        typedef f16 h4 __attribute__((ext_vector_type(4)));
-        const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * 128 + 32 * part + 4 * q8) = o;
+    for (int jj = 0; jj < NJ; ++jj) {
+        if (jj == 1 && !second) break;
+        const float m0 = on ? m1[jj] : -INFINITY;
+        const float l0 = on ? l1[jj] : 0.f;
+        const float mx = wave_max_valu(m0);
+        const float ms_ = mx > -INFINITY ? mx : 0.f;
+        const float w0 = fast_exp2(m0 - ms_);                               // -inf -> 0 (lanes >= ns: 0)
+        // unnormalised sum first, 1 / (sum of w l) at the end: the denominator's reduction runs beside the accumulation
+        v4f32 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (8 * k + h), __builtin_bit_cast(int, w0)));
+            acc += w * __builtin_bit_cast(v4f32, v[jj][k]);
+        }
+        const float den = wave_sum_valu(w0 * l0);
+        const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;    // nothing to attend to: 0
+        // sum over the eight split subsets: lanes l, l ^ 8 (same 16-lane row), then the four rows
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = acc[c];
+            x += MILLION_DPP(x, 0x128);      // row_ror:8
+            acc[c] = fault ? __builtin_nanf("") : rows_sum(x) * inv;
+        }
+        if (lane < 8) {
+            typedef f16 h4 __attribute__((ext_vector_type(4)));
+            const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+            *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g + 2 * jj) * 128 + 32 * part + 4 * q8) = o;
+        }
     }
 }
 
@@ -789,28 +807,32 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     }
     if (p.dbg && tid == 0)      // diagnostics: slot 12 = 1 + "stored plain (every split on this XCD)", slot 13 = 1 + arrival index
         { unsigned long long *d_ = p.dbg + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves * kStampSlots; d_[12] = 1 + (same_xcd ? 1 : 0); d_[13] = 1 + idx; }
-    const int nm = G < ns ? G : ns;                      // mergers: the workgroups that reached their tail last
-    const int j = idx - (ns - nm);
-    if (j >= 0 && ns > 1) {
-        // ---- merger: four waves per head (waves 0-3: head j, waves 4-7: head j + nm, then j + 2 nm ...); every merging wave
-        //      polls the flags itself (lane = split): its loads follow its own match ----
-        // (A dry run of the merge during the poll wait does warm the instruction cache - the merge proper falls from 1.25
-        // to 0.8 us - but takes 1.2 us itself, more than the 0.55 us a merger waits for the last flags: 17.4 vs 16.7 us.)
-        bool polled = false;
-        for (int g = j + (wave >> 2) * nm; g < G; g += 2 * nm) {
-            if (!polled) {
-                __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
-                const int fo = (lane < ns ? lane : 0) * 4;
-                for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
-                    const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
-                    if (__all(f == want)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                polled = true;
-                MILLION_STAMP(p, 11);
+    // ---- the merge: the workgroup whose arrival index is ns - 1, and nobody else (round 4).  Every workgroup it waits for
+    //      has taken its index, i.e. is resident and on its way to its own flag store, and waits for nothing itself: the polls
+    //      end under ANY dispatch order and residency.  (Round 3 let the nm = min(G, ns) highest indices merge one head each:
+    //      a merger other than the last arriver then polls flags of workgroups that may not have been DISPATCHED - with more
+    //      workgroups than resident slots, or two launches sharing the chip, every resident workgroup can be such a merger and
+    //      the launch stalls until the spin bound, then merges stale partials.  The single merger costs the pair one more
+    //      batch of loads, not a second round trip: tail_merge_heads<2>.)
+    //      Four waves per head: waves 0-3 heads 0, 2 | 4, 6 | ..., waves 4-7 heads 1, 3 | 5, 7 | ...; every merging wave polls
+    //      the flags itself (lane = split): its loads follow its own match. ----
+    if (idx == ns - 1 && ns > 1) {
+        bool fault = false;
+        {
+            __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
+            const int fo = (lane < ns ? lane : 0) * 4;
+            fault = true;
+            for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
+                const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                if (__all(f == want)) { fault = false; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
-            tail_merge_head_part(p, b, hk, g, wave & 3, ns, p.ws_part + (long long)bh * ns * p.slot_floats, lane);
+            MILLION_STAMP(p, 11);
         }
+        if (fault && tid == 0) atomicAdd(&g_tail_faults, 1u);      // the heads of this (b, kv head) come out as NaN
+        const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
+        for (int g = wave >> 2; g < G; g += 4)
+            tail_merge_heads<2>(p, b, hk, g, wave & 3, ns, src, lane, g + 2 < G, fault);
     }
     if (idx == ns - 1 && tid == 0) {
         // the workgroup that arrived last: its wave 0 has seen every flag of this launch (or ns == 1), so every workgroup of
@@ -1634,6 +1656,15 @@ bool attn_mfma_shape_ok(const AttnParams &p) {
 
 bool attn_mfma_supported(const AttnParams &p) {
     return attn_mfma_shape_ok(p) && p.v_paged && (p.page_size == 32 || p.page_size == 64 || p.page_size == 128);
+}
+
+// host side of g_tail_faults: waits for the device, returns and clears the count (-1: the runtime refused)
+int read_tail_faults() {
+    unsigned n = 0, zero = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tail_faults), sizeof(n)) != hipSuccess) return -1;
+    if (n && hipMemcpyToSymbol(HIP_SYMBOL(g_tail_faults), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
 }
 
 // A/B knob (million_set_force_generic 2): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only

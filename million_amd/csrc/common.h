@@ -412,6 +412,7 @@ void set_error(const char *fmt, ...);
 int device_cus();
 bool device_once(int family);      // true exactly once per (current device, family 0..7)
 
+int read_tail_faults();             // attn_mfma.hip: merges that ran out of their poll bound since the last call (and clears)
 void set_mfma_policy(int policy);   // attn_mfma.hip: A/B knob behind million_set_force_generic(2 / 3)
 
 }  // namespace million

@@ -248,6 +248,7 @@ int million_debug_bad_page_ids(void) {
 #else
 int million_debug_bad_page_ids(void) { return -1; }
 #endif
+int million_debug_tail_faults(void) { return million::read_tail_faults(); }
 int million_debug_rows_reduce(const float *in64, float *out_max64, float *out_sum64, million_stream_t stream) {
     return launch_rows_reduce_check(in64, out_max64, out_sum64, (hipStream_t)stream);
 }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
             kvr = kvr < p.n_kv ? kvr : p.n_kv - 1;      // clamped: rows past the end are masked below
             const f16 *src = (is_v ? vbase + (long long)kvr * p.v_sn : kbase + (long long)kvr * p.k_sn) + 8 * pch[i];
             const unsigned dst = 2u * kTileBytes * buf + (is_v ? kTileBytes : 0) + 1024u * (pcg % kPieces);
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");      // (nothing else in this kernel uses M0: checked in the ISA)
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
         }
     };
     auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -301,9 +301,15 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
 
 template <int D, int PW>
 static void launch_prefill_t(const PrefillParams &p, long long blocks, int lds, hipStream_t s) {
-    static bool once = false;      // (per process; the attribute is per function, devices share the code object)
-    if (!once) { (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<D, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * D); once = true; }
     hipLaunchKernelGGL((prefill_attn_kernel<D, PW>), dim3((unsigned)blocks), dim3(PW * 64), lds, s, p);
+}
+// dynamic-LDS attribute of the four instances: once per device, under the library's per-device mutex (common.h: device_once)
+static void prefill_attrs_once() {
+    if (!device_once(3)) return;
+    (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 128);
+    (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 128);
+    (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 64);
+    (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 64);
 }
 
 int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
@@ -319,6 +325,7 @@ int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
     if (blocks <= 0) return MILLION_OK;
     if (blocks > 0x7fffffffLL) { set_error("prefill: %lld workgroups", blocks); return MILLION_ERR_SHAPE; }
     const int lds = 4 * kKV * 2 * p.d;      // two buffers of (K tile, V tile)
+    prefill_attrs_once();
     if (p.d == 128) { if (pw == 4) launch_prefill_t<128, 4>(p, blocks, lds, s); else launch_prefill_t<128, 8>(p, blocks, lds, s); }
     else { if (pw == 4) launch_prefill_t<64, 4>(p, blocks, lds, s); else launch_prefill_t<64, 8>(p, blocks, lds, s); }
     const hipError_t e = hipGetLastError();

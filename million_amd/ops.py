@@ -6,6 +6,7 @@ raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import weakref
 from typing import Optional
@@ -432,7 +433,8 @@ class _Plan:
     __slots__ = ("desc", "desc_ref", "ws", "ws_ptr", "ws_bytes", "v_dense", "kc", "kver", "kprep", "vc", "vver", "vprep")
 
 
-_plans: "dict[tuple, _Plan]" = {}
+_plans: "collections.OrderedDict[tuple, _Plan]" = collections.OrderedDict()      # least recently used first
+_MAX_PLANS = 256
 
 
 def _plan_cents(plan: _Plan, key_cents, value_cents, check):
@@ -459,8 +461,11 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
     T = key_codes.shape[2]
     paged = v_page_ids is not None
     stream = _stream()      # part of the signature: the workspace of a plan belongs to one (device, stream)
-    sig = (stream, query.shape, query.dtype, query.is_contiguous(), key_codes.shape[1], key_codes.stride(), key_codes.dtype,
-           value_codes.shape if paged else value_codes.stride(), value_codes.dtype,
+    # Only what does NOT change from one decode step to the next is in the signature: the reference's contiguous
+    # (bs, nh_k, T, M) stores change their batch / head strides at every flush, so those are written into the descriptor
+    # per call (round 3 keyed on them: every new T added a plan, and after 256 plans nothing was cached any more).
+    sig = (stream, query.shape, query.dtype, query.is_contiguous(), key_codes.shape[1], key_codes.stride()[2:], key_codes.dtype,
+           value_codes.shape if paged else value_codes.stride()[2:], value_codes.dtype,
            key_residuals.shape, key_residuals.stride(), key_residuals.dtype, value_residuals.shape, value_residuals.stride(),
            value_residuals.dtype,
            (v_page_ids.shape, v_page_ids.dtype, v_page_ids.is_contiguous(), page_size) if paged else None,
@@ -476,7 +481,9 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
         d = query.shape[3]
         fast_shape = (C in (128, 256) and d in (64, 128) and M in (16, 32, 64) and T > 0 and query.is_contiguous()
                       and key_codes.is_cuda and (not paged or v_page_ids.is_contiguous()))
-        if fast_shape and len(_plans) < 256:      # the call above has validated this signature
+        if fast_shape:                             # the call above has validated this signature
+            while len(_plans) >= _MAX_PLANS:       # least recently used plan (and its workspace) goes
+                _plans.popitem(last=False)
             plan = _Plan()
             if paged:
                 plan.desc = make_attn_desc(query, key_residuals, nh_k=key_residuals.shape[1], M=M, C=C, n_tokens=T, r=int(r),
@@ -494,6 +501,7 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
             plan.vc, plan.vver, plan.vprep = (None, 0, kp) if value_cents is key_cents else (weakref.ref(value_cents), value_cents._version, vp)
             _plans[sig] = plan
         return out
+    _plans.move_to_end(sig)
     if T <= 0:
         raise RuntimeError("decode_attn_planned: empty code store")      # (never cached: fast_shape needs T > 0)
     r = int(r)
@@ -502,6 +510,7 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
     kp, vp = _plan_cents(plan, key_cents, value_cents, check)
     desc = plan.desc
     desc.n_tokens, desc.r = T, r
+    desc.k_stride_b, desc.k_stride_h = key_codes.stride(0), key_codes.stride(1)      # (16-byte alignment: checked by the C entry)
     if plan.v_dense:
         desc.n_pages_cap = (T + 63) // 64
         v_ptr, ids_ptr = _v_pages_of(value_codes, T).data_ptr(), 0

@@ -539,7 +539,9 @@ class PagedPQCache(_CacheBase):
         cap, ps = self.extended_residual_size, self.page_size
         full = self._r_a[layer_idx] >= cap
         lock = self._lockstep(layer_idx)
-        if lock and self._r_a[layer_idx, 0] < ps:
+        # lockstep: the host flushes at r >= page_size, the device (min_r = cap with device lengths) only full windows - the
+        # host mirror must not move when the device will not (a direct call with page_size <= r < cap)
+        if lock and self._r_a[layer_idx, 0] < (cap if use_dev_lengths else ps):
             return
         if not lock and not full.any():
             return

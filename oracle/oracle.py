@@ -172,6 +172,24 @@ def pq_encode_cdist_torch(X, cents):
     return torch.argmin(dis, dim=-1).contiguous().to(torch.uint8).numpy()
 
 
+def pq_encode_direct_torch(X, cents):
+    """The direct form ((x - c) ** 2).sum(-1).argmin over c of sa_encode_4d_keops (pq_utils.py:483-494) as dense torch ops on
+    the host's cores, fp32 (torch.argmin: lowest index on ties).  CPU-baseline timing only (bench.py); the bit-exact
+    checker is pq_encode above."""
+    import torch
+    X = torch.as_tensor(np.asarray(X)).float()
+    C = torch.as_tensor(np.asarray(cents)).float()
+    bs, nh, n, d = X.shape
+    M, c, dm = C.shape
+    Xe = X.reshape(bs * nh * n, M, 1, dm)
+    out = torch.empty(bs * nh * n, M, dtype=torch.uint8 if c <= 256 else torch.int32)
+    step = max(1, (1 << 24) // (M * c * dm))      # ~64 MB of differences per chunk
+    for i0 in range(0, Xe.shape[0], step):
+        e = Xe[i0:i0 + step] - C[None]
+        out[i0:i0 + step] = (e * e).sum(-1).argmin(-1).to(out.dtype)
+    return out.reshape(bs, nh, n, M).numpy()
+
+
 # --------------------------------------------------------------------------------------------------
 # decode (sa_decode_4d)
 # --------------------------------------------------------------------------------------------------

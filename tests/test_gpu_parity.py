@@ -5,6 +5,7 @@ fp16 attention output within 1e-3 relative (rel-L2) and mean-abs < 1e-3 (the ref
 scripts/utils/pq_utils.py:374-379) of the fp64 oracle.  Nothing here reads /root/reference.
 """
 import ctypes
+import time
 import hashlib
 import json
 
@@ -482,7 +483,7 @@ def test_harness_graph_replay_matches_eager(env):
     (24608, 3, 32, 8),      # 26 units per split: waves with 3 units run one masked phantom unit
     (40960, 77, 8, 8),      # 40 units per split: every wave has five; G = 1
     (33000, 128, 64, 8),    # ragged end inside a unit; G = 8
-    (40961, 5, 32, 8),      # one token past the pipelined range: grouped kernel, several groups per wave
+    (40961, 5, 32, 8),      # 41 units per split: waves 0-1 carry a sixth unit (one whole round of four + two single units)
 ])
 def test_attn_long_context(T, r, nh, nhk, env, oracle):
     torch, ops = env
@@ -1302,6 +1303,37 @@ def test_attn_window_of_256_rows_on_mfma(T, r, start, M, env, oracle):
         out2 = fn(t["q"], t["k_codes"], t["k_cents"], t["k_res"][:, :, :r], torch.from_numpy(ids).cuda(),
                   torch.from_numpy(vpool).cuda(), t["v_cents"], t["v_res"][:, :, :r], r, ids.shape[2], ps, po, pl)
         _check(out2.cpu().numpy(), gold, "bindings Lt256")
+
+
+@pytest.mark.parametrize("bs,cap,T,r", [(32, 256, 1500, 200), (20, 128, 2100, 77), (40, 256, 700, 256)])
+def test_attn_more_workgroups_than_resident_slots(bs, cap, T, r, env, oracle):
+    """Grids with more workgroups than the chip holds at once (one 138-KiB workgroup per CU) AND several splits per (b, kv
+    head): bs * nh_k = 256 with a 256-row window (two splits forced by the window), 160 pairs x 2 splits, 320 pairs x 2.  With
+    a multiple of 8 pairs every split-0 workgroup is dispatched before any split-1 workgroup: round 3's tail let a split-0
+    workgroup poll for the flag of a split-1 workgroup that could not be dispatched.  The merge now belongs
+    to the last-arriving workgroup alone; no poll may run out of its bound (million_debug_tail_faults)."""
+    torch, ops = env
+    from million_amd import _lib
+    nh, nhk, ps, M = 32, 8, 64, 64
+    c = synth.attn_case(9400 + bs + T % 13, bs, nh, nhk, 128, M, 256, T, r, Lt=cap)
+    gold = oracle.decode_attn(**c)
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    _lib.load().million_debug_tail_faults()      # clear
+    t0 = time.perf_counter()
+    for _ in range(3):                            # the workspace's records must be at rest after each launch
+        out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda(), kp, vp, t["k_res"],
+                                 t["v_res"], r, M=M, C=256, n_tokens=T, k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0, "a launch stalled in its tail"
+    assert _lib.load().million_debug_tail_faults() == 0
+    _check(out.cpu().numpy(), gold, f"bs={bs} cap={cap}")
+    desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=256, n_tokens=T, r=r, k_paged=True, v_paged=True,
+                              page_size=ps, n_pages_cap=ids_t.shape[2])
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
 
 
 @pytest.mark.parametrize("M,T,r,bs", [(64, 5000, 17, 1), (32, 40000, 128, 1), (64, 33000, 64, 2), (64, 0, 40, 1), (32, 100, 1, 1)])

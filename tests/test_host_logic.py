@@ -3,6 +3,7 @@ multi-process timing path of bench.py on the gloo backend (world size 2)."""
 import json
 import os
 import socket
+from pathlib import Path
 import time
 
 import pytest
@@ -366,3 +367,24 @@ def test_paged_cache_step_kinds_state_machine_on_cpu():
     assert c.next_step_kind() == "flush"
     c.release(1)                                  # a recycled slot loses its flags with its lengths
     assert c._pre_a[:, 1].tolist() == [0] * 4
+
+
+def test_make_install_pth_resolves_bindings_without_pythonpath(tmp_path):
+    """`make install` (tools/install_pth.py, reference makefile:1-4): with the .pth file in a site directory, `import bindings`
+    and `import million_amd` resolve from an unrelated working directory with no PYTHONPATH; --uninstall removes it."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    site_dir = tmp_path / "site"
+    r = subprocess.run([sys.executable, str(root / "tools" / "install_pth.py"), "--target", str(site_dir)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (site_dir / "million_hip.pth").read_text().strip() == str(root)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    code = ("import site, sys; site.addsitedir(%r); import bindings, million_amd; "
+            "print(bindings.__file__); "
+            "assert hasattr(bindings, 'flash_decoding_allocated_buffer_f16u8_Ns32Lt128d128M64C256')") % str(site_dir)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stderr
+    assert str(root) in r.stdout
+    r = subprocess.run([sys.executable, str(root / "tools" / "install_pth.py"), "--target", str(site_dir), "--uninstall"], capture_output=True, text=True)
+    assert r.returncode == 0 and not (site_dir / "million_hip.pth").exists()
