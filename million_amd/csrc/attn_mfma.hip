@@ -95,7 +95,10 @@ __device__ __forceinline__ float lane_bcast(float x, int lane_const) {       // 
 // of more than 8 query heads (wave-uniform branch).  Rows of heads >= G are scaled by whatever their idle column holds:
 // they are never read.  One ds_bpermute per register row (no SGPRs: 16 v_readlane results spilled scalar registers in
 // the streaming loop).
-__device__ __forceinline__ void rescale_heads(v16f32 (&O)[2][2], float alpha, int G, int lane) {
+// PV = parity-V accumulators (streaming kernel, M = 64; see "parity-V" below): only the tiles O[n][0] exist, tile rows are
+// (parity of the dim, head): register 4 j + rho of lane (h, col) = row 8 j + 4 h + rho = parity j >> 1, head 8 (j & 1) + 4 h + rho.
+template <bool PV = false>
+__device__ __forceinline__ void rescale_heads(v16f32 (&O)[2][PV ? 1 : 2], float alpha, int G, int lane) {
     const int sel = lane < 32 ? 0 : 16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -104,9 +107,15 @@ __device__ __forceinline__ void rescale_heads(v16f32 (&O)[2][2], float alpha, in
         for (int rho = 0; rho < 4; ++rho) {
             const float f = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel + 4 * (8 * j + rho), __builtin_bit_cast(int, alpha)));
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n) {
+                if (PV) {
+                    O[n][0][4 * j + rho] *= f;
+                    O[n][0][4 * (j + 2) + rho] *= f;
+                } else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) O[n][kk][4 * j + rho] *= f;
+                    for (int kk = 0; kk < (PV ? 1 : 2); ++kk) O[n][kk][4 * j + rho] *= f;
+                }
+            }
         }
     }
 }
@@ -543,6 +552,69 @@ __device__ __forceinline__ void value_res_tile(const ResTile &t, const float (&p
     }
 }
 
+// ---- parity-V (round 4): the value product without the pack -------------------------------------------------------
+// A gathered V word is (dim 2m, dim 2m + 1) of ONE token; the value MFMA's operand register wants two reduction indices of one
+// column.  Rounds 1-3 re-packed: 8 gathers -> 8 v_perm -> B0 (even dims), B1 (odd dims), two MFMAs, 64 accumulator registers.
+// Here the reduction index IS (token, parity of the dim): the gathered word is the B operand as it stands (4 gathers = one
+// lane's 8 reduction slots = 4 tokens), and the zero pattern moves to the cheap side - tile row (parity p, head g) holds
+// P[g][token] in half p of the register and 0 in the other half, so that
+//   D[(p, g)][m] = sum over (token, e) of P[g][token] [e == p] * Vhat[token][2m + e] = O[g][2m + p].
+// Per 32-token unit: 32 gathers, 32 address v_perm, 16 placement v_perm, 8 MFMA (one per 8 tokens x 32 subspaces), 32
+// accumulator registers - against 32 + 32 + 32 pack + 8 and 64 (tools/micro/core_micro.hip: +12 % units per SIMD and us).
+// Tile rows: r = 16 p + g (g < 16 heads); lane (h, r) of the A operand, step s (tokens 16h + 4s + t, t = 0..3): register t.
+// The score tiles leave, in lane (q4 = 2h + p', g), the probabilities of tokens 16h + 8p' + x, x = 0..7: W[k] = cvt_pk(x = 2k,
+// 2k + 1); swap16_self hands every lane pair (p' = 0, 1) both rows' W (E: tokens 16h + 0..7, F: 16h + 8..15); sel_lo / sel_hi
+// (lane constants, by the lane's OWN row parity) move one half of a W into the lane's half of the register.
+struct ParA { unsigned E[4], F[4]; };
+__device__ __forceinline__ void value_prep_par(const float (&pr)[8], ParA &pa) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h2 t = {(f16)pr[2 * k], (f16)pr[2 * k + 1]};
+        const v2u y = swap16_self(__builtin_bit_cast(unsigned, t));
+        const unsigned y0 = y[0], y1 = y[1];
+        pa.E[k] = y0;
+        pa.F[k] = y1;
+    }
+}
+// A operand of token step s (0..3)
+__device__ __forceinline__ v8f16 value_A_par(const ParA &pa, int s, unsigned sel_lo, unsigned sel_hi) {
+    const unsigned w0 = s < 2 ? pa.E[2 * (s & 1)] : pa.F[2 * (s & 1)], w1 = s < 2 ? pa.E[2 * (s & 1) + 1] : pa.F[2 * (s & 1) + 1];
+    return as_v8f16(__builtin_amdgcn_perm(0u, w0, sel_lo), __builtin_amdgcn_perm(0u, w0, sel_hi),
+                    __builtin_amdgcn_perm(0u, w1, sel_lo), __builtin_amdgcn_perm(0u, w1, sel_hi));
+}
+__device__ __forceinline__ void par_selectors(int lane, unsigned &sel_lo, unsigned &sel_hi) {
+    const bool odd = (lane >> 4) & 1;      // v_perm selectors: bytes 0-3 = the W register, 0x0c = zero
+    sel_lo = odd ? 0x01000c0cu : 0x0c0c0100u;
+    sel_hi = odd ? 0x03020c0cu : 0x0c0c0302u;
+}
+// the 4 gathers of value step (token step s, subspace half n): tokens 16h + 4s + t of subspace 32n + c32
+__device__ __forceinline__ void v_gather_par(const v4u (&vc)[2], int s, int n, unsigned vconst0, unsigned vconst1, unsigned (&e)[4]) {
+    const unsigned vconst = n ? vconst1 : vconst0;
+    const unsigned w = vc[n][s];
+    e[0] = lds32(__builtin_amdgcn_perm(w, vconst, 0x03020400u));
+    e[1] = lds32(__builtin_amdgcn_perm(w, vconst, 0x03020500u));
+    e[2] = lds32(__builtin_amdgcn_perm(w, vconst, 0x03020600u));
+    e[3] = lds32(__builtin_amdgcn_perm(w, vconst, 0x03020700u));
+}
+// residual tile in the parity form: t.v[n][j] (rows 8h + j, dims (2m, 2m + 1)) IS the B operand of step s = j >> 2; pr[rho] =
+// probability of row 4 q4 + rho = 8h + 4p' + rho: step 0's rows sit in the even lane rows, step 1's in the odd ones
+__device__ __forceinline__ void value_res_tile_par(const ResTile &t, const float (&pr)[4], unsigned sel_lo, unsigned sel_hi, v16f32 (&O)[2][1]) {
+    h2 t0 = {(f16)pr[0], (f16)pr[1]}, t1 = {(f16)pr[2], (f16)pr[3]};
+    const v2u y0 = swap16_self(__builtin_bit_cast(unsigned, t0));
+    const v2u y1 = swap16_self(__builtin_bit_cast(unsigned, t1));
+    const unsigned e0 = y0[0], f0 = y0[1], e1 = y1[0], f1 = y1[1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned w0 = s ? f0 : e0, w1 = s ? f1 : e1;
+        const v8f16 A = as_v8f16(__builtin_amdgcn_perm(0u, w0, sel_lo), __builtin_amdgcn_perm(0u, w0, sel_hi),
+                                 __builtin_amdgcn_perm(0u, w1, sel_lo), __builtin_amdgcn_perm(0u, w1, sel_hi));
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            O[n][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, as_v8f16(t.v[n][4 * s], t.v[n][4 * s + 1], t.v[n][4 * s + 2], t.v[n][4 * s + 3]),
+                                                             O[n][0], 0, 0, 0);
+    }
+}
+
 // =====================================================================================================
 // Tail shared by the MFMA kernels (round 3): wave partials -> LDS -> the split's partial -> workspace -> merge.
 //
@@ -692,9 +764,9 @@ __device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int
     }
 }
 
-template <int MS = 64>
+template <int MS = 64, bool PV = false>
 __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *smem, int b, int hk, int split, int G, int tid,
-                                                  int lane, int wave, bool dbg_on, v16f32 (&O)[2][2], float m_run, float l_run,
+                                                  int lane, int wave, bool dbg_on, v16f32 (&O)[2][PV ? 1 : 2], float m_run, float l_run,
                                                   TailReq &treq) {
 #define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
     const int ns = p.nslots;
@@ -722,6 +794,18 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     {
         const bool hi = lane >= 32;
         const int c32 = lane & 31;
+        if (PV) {      // parity-V tiles O[n][0]: register 4 j + rho = row 8 j + 4 hi + rho = (parity j >> 1, head 8 (j & 1) + 4 hi + rho)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho) {
+                    const int g = 8 * (j & 1) + (hi ? 4 + rho : rho);
+                    if (g < G) {
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) mine[g * 128 + 2 * (32 * n + c32) + (j >> 1)] = O[n][0][4 * j + rho];
+                    }
+                }
+        } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j)                      // tile rows 8 j + 4 hi + rho = register 4 j + rho; j = 1: groups above 8 heads
 #pragma unroll
@@ -731,10 +815,11 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
+                        for (int kk = 0; kk < (PV ? 1 : 2); ++kk)
                             mine[g * 128 + (MS == 64 ? 2 * (32 * n + c32) + kk : 4 * c32 + 2 * n + kk)] = O[n][kk][4 * j + rho];
                 }
             }
+        }
         if (lane < G) {                                  // lane g: row q' = 0, col g
             mine[G * 128 + lane] = m_run;
             mine[G * 128 + kMaxGMfma + lane] = l_run;
@@ -1163,8 +1248,8 @@ __device__ __forceinline__ void v_step(const unsigned (&e)[8], const unsigned (&
 // =====================================================================================================
 // online softmax over N new scores of this lane's column (head): updates (m_run, l_run), rescales O when a
 // running maximum moves, turns the scores into probabilities in place
-template <int N>
-__device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, float &l_run, v16f32 (&O)[2][2], int G, int lane) {
+template <int N, bool PV = false>
+__device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, float &l_run, v16f32 (&O)[2][PV ? 1 : 2], int G, int lane) {
     float mx = sc[0];
 #pragma unroll
     for (int i = 1; i < N; ++i) mx = fmaxf(mx, sc[i]);
@@ -1173,7 +1258,7 @@ __device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, flo
     const float m_safe = m_new > -INFINITY ? m_new : 0.f;
     const float alpha = fast_exp2(m_run - m_safe);
     if (__any(m_new > m_run && m_run > -INFINITY)) {
-        rescale_heads(O, alpha, G, lane);
+        rescale_heads<PV>(O, alpha, G, lane);
     }
     float ls = 0.f;
 #pragma unroll
@@ -1202,14 +1287,17 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // are kept in registers so that the common path recomputes neither.
 struct SoftRef {
     float m, l, neg_ref, thr_raw;
+    float idle = 0.f;      // -inf in the lanes of score columns >= G (no query head): their probabilities come out as exact zeros, so
+                           // the idle rows of the value MFMA's A operand multiply zeros (round 4: the MFMAs set the chip's clock -
+                           // tools/micro/core_micro.hip "MFMA -> 1 VALU": 1.80 -> 2.31 GHz - and zero operands draw less)
     __device__ __forceinline__ void set(float m_, float l_, float inv_c) {
         m = m_; l = l_;
-        neg_ref = m_ > -INFINITY ? -m_ : 0.f;
+        neg_ref = (m_ > -INFINITY ? -m_ : 0.f) + idle;
         thr_raw = (m_ + 8.0f) * inv_c;          // -inf while nothing has been seen: the first finite score moves it
     }
 };
-template <int N>
-__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float inv_c, SoftRef &st, v16f32 (&O)[2][2],
+template <int N, bool PV = false>
+__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float inv_c, SoftRef &st, v16f32 (&O)[2][PV ? 1 : 2],
                                                    int G, int lane) {
     static_assert(N == 8, "one 32-token unit: 8 scores per lane");
     float mx = max3_raw(sc[0], sc[1], sc[2]);
@@ -1221,7 +1309,7 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
         const float m_safe = m_new > -INFINITY ? m_new : 0.f;
         const float alpha = fast_exp2(st.m - m_safe);
         if (__any(m_new > st.m && st.m > -INFINITY)) {
-            rescale_heads(O, alpha, G, lane);
+            rescale_heads<PV>(O, alpha, G, lane);
         }
         st.set(m_new, st.l * alpha, inv_c);
     }
@@ -1305,8 +1393,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     typedef typename StreamTypes<MS>::Unit Unit;
     typedef typename StreamTypes<MS>::E EBuf;
     constexpr int kLog2M = MS == 64 ? 6 : 5;
-    constexpr int NV = MS == 64 ? 4 : 2;       // value steps per unit (16 tokens each for M = 64 subspaces in two halves)
+    constexpr bool PV = MS == 64;              // parity-V value product (see "parity-V" above); M = 32 keeps the packed form
+    constexpr int NV = PV ? 8 : 2;             // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1)
     constexpr int SPV = 8 / NV;                // score stages that ride along with one value step
+    constexpr int VD = PV ? 2 : 1;             // value steps the V gathers run ahead of their MFMA (a parity-V step is 4 gathers +
+                                               // 1 MFMA, ~100 cycles of issue: one step ahead does not cover an LDS round trip)
     constexpr int NT = 8 >> (8 - CL2);         // 16-byte pieces of a codebook image per thread (C = 256: 64 KiB, C = 128: 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1441,6 +1532,25 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
     UNIT_REQ(0, 0)
     UNIT_REQ(1, 1)
+#if MILLION_EXP & 1
+    // A/B: TOUCH the lines of rounds 2 and 3 (one dword per 128-byte line, result never read): the real requests of those
+    // rounds go out ~2-3 us later and should then find their lines on the way or in L2
+    if (p.ps_shift == 6 && k_paged) {
+        typedef const volatile __attribute__((address_space(1))) unsigned *gptr_vu;
+        constexpr int NK = (32 << kLog2M) / 128, NVL = (MS * 64) / 128;
+#pragma unroll
+        for (int jj = 2; jj < 4; ++jj) {
+            const int jc_ = jj < n_mine ? jj : j_last;
+            const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_), pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);
+            const gptr_u8 kb_ = uniform_ptr(p.k_codes + (((pk_ << 6) + tin) << kLog2M));
+            const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + 6)));
+            const bool is_k = lane < NK;
+            const int li = is_k ? lane : (lane - NK < NVL ? lane - NK : 0);
+            const gptr_u8 a_ = (is_k ? kb_ : vb_) + 128u * li;
+            (void)*(gptr_vu)a_;      // volatile: the load is issued, nothing ever waits for its data
+        }
+    }
+#endif
     // (Round 3, tools/ab_build.py: units 2 and 3 requested here too - all four ring slots up front - 19.5 us instead of 16.8 at
     // one request, 25.2 vs 24.0 at two; right behind the codebook barrier: 18.1 / 23.9.  The CU's request queue is in order:
     // what is asked for before the codebooks are in LDS delays the barrier every wave waits at.  Also without effect (+-0.15 us
@@ -1460,11 +1570,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     STAMP(1);
 
     float m_run = -INFINITY, l_run = 0.f;
-    v16f32 O[2][2];
+    v16f32 O[2][PV ? 1 : 2];      // parity-V: one 32 x 32 tile per subspace half
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < (PV ? 1 : 2); ++kk)
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
     if (append_wave) {
@@ -1474,15 +1584,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         *(h2 *)(p.k_res_w + o) = new_k;
         *(h2 *)(p.v_res_w + o) = new_v;
     }
+    unsigned sel_lo, sel_hi;      // parity-V: where a probability goes in this lane's A-operand registers
+    par_selectors(lane, sel_lo, sel_hi);
     if (has_res) {      // residual tile of this wave first: it needs neither codebook
         float scr[4];
         score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
-        softmax_online<4>(scr, m_run, l_run, O, G, lane);
-        value_res_tile(rt, scr, O);
+        softmax_online<4, PV>(scr, m_run, l_run, O, G, lane);
+        if constexpr (PV) value_res_tile_par(rt, scr, sel_lo, sel_hi, O);
+        else value_res_tile(rt, scr, O);
     }
     STAMP(2);
     const float inv_c = 1.0f / p.scale_log2e;
     SoftRef sr;
+    sr.idle = c16 < G ? 0.f : -INFINITY;
     sr.set(m_run, l_run, inv_c);
 
     const unsigned kbase = (unsigned)q4 * (64u << CL2);      // quarter q4 of the K row image: its 16 (M = 64) / 8 (M = 32) subspaces
@@ -1490,19 +1604,36 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);      // M = 64 only
 
     unsigned a[2][4], P[4];
-    EBuf e[2];
+    EBuf e[2];          // packed form (M = 32)
+    unsigned e4[4][4];  // parity-V (M = 64): the gathers of value step i sit in e4[i & 3], two steps ahead of their MFMA
+    ParA pa;
+    v8f16 Acur;
     float sc[8];
 #define KG(SL, ST) st_kgather<CL2>(ring[SL], ST, kbase, a[(ST) & 1])
 #define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
         as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
     // value steps run token-step major: i -> st = 2n + s with s = i / (NV / 2), so that P serves both s = 0 steps, is
     // moved on in place (value_next_step), and then serves both s = 1 steps
-#define VST(I) (MS == 64 ? ((((I) & 1) << 1) | ((I) >> 1)) : (I))
-#define VG(SL, I) st_vgather(ring[SL], VST(I), vconst0, vconst1, e[(I) & 1])
+#define VG(SL, I)                                                                                                  \
+    do {                                                                                                           \
+        if constexpr (PV) v_gather_par(ring[SL].v, (I) >> 1, (I) & 1, vconst0, vconst1, e4[(I) & 3]);              \
+        else st_vgather(ring[SL], (I), vconst0, vconst1, e[(I) & 1]);                                              \
+    } while (0)
 #define VS(I)                                                                                                      \
     {                                                                                                              \
-        if ((I) == NV / 2) value_next_step(P);                                                                     \
-        st_vstep(e[(I) & 1], P, VST(I), O);                                                                        \
+        if constexpr (PV) {                                                                                        \
+            if (((I) & 1) == 0) Acur = value_A_par(pa, (I) >> 1, sel_lo, sel_hi);                                  \
+            O[(I) & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                                \
+                Acur, as_v8f16(e4[(I) & 3][0], e4[(I) & 3][1], e4[(I) & 3][2], e4[(I) & 3][3]), O[(I) & 1][0], 0, 0, 0); \
+        } else {                                                                                                   \
+            if ((I) == NV / 2) value_next_step(P);                                                                 \
+            st_vstep(e[(I) & 1], P, (I), O);                                                                       \
+        }                                                                                                          \
+    }
+#define VPREP()                                                                                                    \
+    {                                                                                                              \
+        if constexpr (PV) value_prep_par(sc, pa);                                                                  \
+        else value_prep(sc, P);                                                                                    \
     }
     // raw scores of round J out of the accumulators; only the unit that holds token T - 1 (wave-uniform) is masked; a
     // round whose first token is past T - 1 (only the prologue of a wave without whole rounds meets one) gives -inf
@@ -1526,7 +1657,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                           \
             VS(i)                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
-            if (i + 1 < NV) VG(U4, i + 1); else VG(((U4) + 1) & 3, 0);                                             \
+            if (i + VD < NV) VG(U4, i + VD); else VG(((U4) + 1) & 3, i + VD - NV);                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             _Pragma("unroll") for (int k = 0; k < SPV; ++k) {                                                      \
                 KM(SPV * i + k);                                                                                   \
@@ -1537,12 +1668,12 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         }                                                                                                          \
         UNIT_REQ_V(U4, (J) + 4)                                                                                    \
         SCORES_OUT((J) + 1)                                                                                        \
-        softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                        \
-        value_prep(sc, P);                                                                                         \
+        softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                       \
+        VPREP()                                                                                                    \
     }
 #define VALUE_ALONE(U4)                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                               \
-        if (i + 1 < NV) VG(U4, i + 1);                                                                             \
+        if (i + VD < NV) VG(U4, i + VD);                                                                           \
         VS(i)                                                                                                      \
     }
     // One unit on its own (the up to three units a wave has beyond its whole rounds of four): scores, softmax, values,
@@ -1557,9 +1688,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             if (st + 2 < 8) KG(SL, st + 2);                                                                        \
         }                                                                                                          \
         SCORES_OUT(J)                                                                                              \
-        softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                        \
-        value_prep(sc, P);                                                                                         \
-        VG(SL, 0);                                                                                                 \
+        softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                       \
+        VPREP()                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < VD; ++k) VG(SL, k);                                                  \
         VALUE_ALONE(SL)                                                                                            \
     }
     const int n_whole = n_mine >> 2, n_rem = n_mine & 3;      // whole rounds of four units + up to three more
@@ -1586,29 +1717,34 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 for (int i = 0; i < 8; ++i) sc[i] = -INFINITY;
             }
         }
-        softmax_online_raw<8>(sc, p.scale_log2e, inv_c, sr, O, G, lane);
-        value_prep(sc, P);
+        softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane);
+        VPREP()
         STAMP(16);
         UNIT_REQ(3, 3)
         if (n_whole > 0) {
-            VG(0, 0);
+#pragma unroll
+            for (int k = 0; k < VD; ++k) VG(0, k);
             KG(1, 0);
             KG(1, 1);
-            int j = 0;
+            // The first round's three blocks, then the loop ROTATED by three (round 4): the path of a wave with ONE whole round
+            // (the headline shape at one request) joins the loop's exit with only ring slot 3 and the softmax state live.  With
+            // the loop in front of these three blocks (rounds 2-3) the whole ring was live across it on that path, and the
+            // parity-V build spilled 53 registers around the loop - scratch, which alone cost ~9 us per launch.
+            BLOCK(0, 0)
+            BLOCK(1, 1)
+            BLOCK(2, 2)
+            int j = 3;
             for (int w = 1; w < n_whole; ++w) {
+                BLOCK(3, j)
+                ++j;
                 BLOCK(0, j)
                 ++j;
                 BLOCK(1, j)
                 ++j;
                 BLOCK(2, j)
                 ++j;
-                BLOCK(3, j)
-                ++j;
                 if (w == 1) STAMP(17);
             }
-            BLOCK(0, j)
-            BLOCK(1, j + 1)
-            BLOCK(2, j + 2)
             tail_request(p, bh, p.nslots, wave, lane, treq);      // ~3 us ahead of the point where the tail needs the answers
             STAMP(19);
             VALUE_ALONE(3)
@@ -1623,7 +1759,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef KM
 #undef VG
 #undef VS
-#undef VST
+#undef VPREP
 #undef SCORES_OUT
 #undef BLOCK
 #undef VALUE_ALONE
@@ -1631,7 +1767,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef UNIT_REQ_K
 #undef UNIT_REQ_V
     STAMP(3);
-    merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l, treq);
+    merge_and_publish<MS, PV>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l, treq);
 #undef STAMP
 }
 
