@@ -1821,14 +1821,30 @@ static int mfma_splits(const AttnParams &p) {
     if (ns > units) ns = units;
     const int ns_window = (p.rcap + kNW * kResRows - 1) / (kNW * kResRows);      // splits the residual window needs
     if (ns < ns_window) ns = ns_window;      // (a split beyond the last unit just has no code units)
+    // The streaming kernel preloads the page ids of a wave's first 64 rounds (one vector load, lane = round): a call with more
+    // rounds per wave - many (b, kv head) pairs AND a long context, e.g. 16 requests x 8 kv heads at 40K tokens - gets more
+    // splits instead of the grouped kernel (round 4; rounds 2-3 dropped such calls to the grouped kernel, C = 128 even to the
+    // scalar one).  The grid then holds more workgroups than CUs; the tail's single merger waits only for workgroups that
+    // have started, so any dispatch order is fine.  64 splits x 64 rounds x 256 tokens = 1M tokens per (b, kv head).
+    if (p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) > 64) {
+        while (ns < kMaxSplits && (p.T + ns * 256 - 1) / (ns * 256) > 64) ++ns;
+        // more workgroups than CUs now: prefer a grid that is a whole number of chip-fulls (128 pairs: 4 splits = 2 x 256
+        // workgroups of 40 rounds instead of 3 splits = 256 + 128 of 53), if that costs at most twice the splits
+        for (int n2 = ns; n2 <= 2 * ns && n2 <= kMaxSplits; ++n2)
+            if ((long long)bh * n2 % cus == 0) { ns = n2; break; }
+    }
     return ns;
 }
 // streaming kernel: rounds per wave = ceil(T / (ns * 256 tokens)) must fit the 64 page ids a wave preloads
 static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64; }
 
-// C = 128 runs on the streaming kernel only: without it (T = 0, more than 64 rounds per wave) the call goes back to the caller
+// C = 128 runs on the streaming kernel only: without it (T = 0, more than 1M tokens) the call goes back to the caller
 bool attn_mfma_handles(const AttnParams &p) {
     return attn_mfma_supported(p) && (p.C != 128 || mfma_stream_ok(p, mfma_splits(p)));
+}
+// the call will run the STREAMING kernel (not the grouped fallback): million_attn_kernel_kind
+bool attn_mfma_streams(const AttnParams &p) {
+    return attn_mfma_supported(p) && g_mfma_policy == 0 && mfma_stream_ok(p, mfma_splits(p));
 }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {

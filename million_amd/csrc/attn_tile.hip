@@ -6,18 +6,22 @@
 // flash_decoding_residual_kernel + flash_decoding_reduce_kernel, Interface.template.cu:26-120, Kernel.cuh:11-166,
 // 1038-1270), written once for every sub-vector width d_m in {1, 2, 4, 8}:
 //   * both codebooks (row image [m][c][d_m], fp16) sit in LDS for the whole kernel;
-//   * a wave walks 16-token tiles on its own (no workgroup barrier inside the loop).  Per tile it
-//       1. dequantises the K codes into a fp16 tile K^[16 tokens][d] in LDS (lane = (token, quarter of the code row):
-//          one codebook entry per code byte, written back as 16-byte pieces),
-//       2. scores: v_mfma_f32_16x16x32_f16, A = K^ rows (one ds_read_b128 per 32 dims), B = the query heads,
-//       3. online softmax in the exp2 domain, fp32 (head = lane column; the probabilities are already laid out as the
-//          B operand of step 5),
-//       4. dequantises the V codes into the transposed tile V^T[d][16 tokens] over the same LDS bytes (lane = (pair of
-//          dims, 8 tokens): eight 4-byte entry reads, eight v_perm to put the tokens of one dim side by side),
-//       5. values: v_mfma_f32_16x16x16_f16, A = V^T rows (dims), B = P -> O^T[dim][head]: the running rescale is
-//          lane-local;
-//   * the residual window goes through the same five steps with the tile filled from the fp16 rows instead of the
-//     codebook (one extra workgroup per (b, kv head), as in attn_generic.hip), the fused append included;
+//   * a wave walks 16-token tiles on its own (no workgroup barrier inside the loop).  Round 4: a code tile no longer goes
+//     through LDS (rounds 1-3 dequantised K^ and V^T into an LDS tile and read them back: four dependent LDS round trips per
+//     tile, 3-15 % of the HBM peak) - the centroids go from the LDS-resident codebooks STRAIGHT into MFMA operands, as in
+//     attn_mfma.hip:
+//       1. scores: lane (quarter q4 of the dims, token): the lane's M/4 code bytes are its quarter of the code row; stage s
+//          (8 dims of the quarter) gathers 8/d_m entries of the K row image - one ds_read_b128 / two b64 / four b32 / eight
+//          u16 - which ARE the A operand of v_mfma_f32_16x16x32_f16 (B = the query heads, same dim order);
+//       2. online softmax in the exp2 domain, fp32 (head = lane column; the probabilities are already laid out as the B
+//          operand of step 4);
+//       3. values: lane (4 tokens q4, subspace m = 16 cg + c16): 4 gathers of the V col image per column group cg (bank =
+//          subspace); for every dim e of the sub-vector the four tokens' halves are packed (2 v_perm) into the A operand of
+//          v_mfma_f32_16x16x16_f16 (rows = 16 subspaces, k = 16 tokens), B = P -> tile (cg, e) of O^T[(16 cg + row) d_m + e][head]:
+//          d/16 accumulator tiles as before, the running rescale is lane-local;
+//     M/4 + M/4 gathers, d/8 packs and d/32 + d/16 MFMAs per tile and wave; up to 16 query heads per launch (the 16 columns);
+//   * the residual window keeps the LDS tile (one extra workgroup per (b, kv head), as in attn_generic.hip: K rows -> K^ tile ->
+//     scores, V rows -> transposed V^T tile -> values), the fused append included;
 //   * the waves' partials are merged through LDS, the workgroups' through the workspace by the last arriver
 //     (common.h: publish_and_merge), exactly as in the other two kernels.
 // Code bytes are read once per kv head (all G = nh / nh_k query heads share a workgroup) straight into registers,
@@ -32,10 +36,7 @@ typedef _Float16 t4f16 __attribute__((ext_vector_type(4)));
 typedef float t4f32 __attribute__((ext_vector_type(4)));
 typedef unsigned t4u __attribute__((ext_vector_type(4)));
 
-// Waves per workgroup (template parameter TW): the two codebooks (d*C*2 bytes each) decide.  d = 128: 128 KiB of tables
-// leave room for four 6-KiB wave tiles (one workgroup of 4 waves per CU).  d = 64: 64 KiB of tables: either two
-// workgroups of 4 waves per CU (best throughput: 57 vs 62 us at 4 requests x 32K, M = 32) or one workgroup of 16 waves
-// (fewer tiles per wave, shorter launch when there is little work per CU: 23.9 vs 26.5 us at 1 request).
+// Waves per workgroup (template parameter TW): see launch_attn_tile.  Only the residual-window workgroup uses LDS wave tiles.
 constexpr int kTT = 16;    // tokens per wave tile
 
 template <int D>
@@ -45,9 +46,18 @@ struct TileGeom {
     static constexpr int kTile = (kTT * kKRow > D * kVRow) ? kTT * kKRow : D * kVRow;
 };
 
-static size_t tile_lds_bytes(int d, int C, int slot_floats, int waves) {
+// LDS: [region][partial of the workgroup][flag].  region = the two codebooks (code workgroups), reused after the loop as the
+// waves' merge scratch; the residual workgroup (no codebooks) keeps its K^ / V^T wave tiles there.
+static size_t tile_region_bytes(int d, int C, int G, int waves) {
     const size_t tile = d == 128 ? TileGeom<128>::kTile : TileGeom<64>::kTile;
-    return 2 * (size_t)d * C * 2 + waves * tile + (size_t)slot_floats * 4 + 16;
+    size_t r = 2 * (size_t)d * C * 2;
+    if (waves * tile > r) r = waves * tile;
+    const size_t wf = (size_t)waves * (G * d + 2 * G) * 4;
+    if (wf > r) r = wf;
+    return (r + 15) / 16 * 16;
+}
+static size_t tile_lds_bytes(int d, int C, int slot_floats, int waves, int G) {
+    return tile_region_bytes(d, C, G, waves) + (size_t)slot_floats * 4 + 16;
 }
 
 __device__ __forceinline__ float fast_exp2_tile(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: exp2(-inf) = 0
@@ -59,14 +69,15 @@ __device__ __forceinline__ void lds_phase() {      // LDS writes of this wave be
 }
 
 template <int D, int DM, int TW>
-__global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(AttnParams p) {
+__global__ __launch_bounds__(TW * 64, TW / 4) void attn_tile_kernel(AttnParams p) {
     constexpr int kTW = TW;
     constexpr int M = D / DM;
     constexpr int NS = D / 32;                 // score stages (32 dims each)
     constexpr int NC = D / 16;                 // output tiles of 16 dims
     constexpr int KD = M / 16;                 // K code dwords per lane and tile: lane (token, quarter) owns M/4 bytes
-    constexpr int NTASK = D / 64;              // V tasks per lane and tile: (d/2 dim pairs) x (2 token octets) / 64
-    constexpr int VR = DM == 1 ? 2 : 1;        // V page rows a task reads (a pair of dims spans two subspaces at d_m = 1)
+    constexpr int CG = M / 16;                 // column groups of 16 subspaces: V code dwords per lane and tile (4 tokens each)
+    constexpr int EW = DM >= 2 ? DM / 2 : 1;   // dwords per gathered codebook entry
+    constexpr int NTASK = D / 64;              // residual window: V tasks per lane and tile: (d/2 dim pairs) x (2 token octets) / 64
     constexpr int kKRow = TileGeom<D>::kKRow, kVRow = TileGeom<D>::kVRow, kTile = TileGeom<D>::kTile;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -83,8 +94,12 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
 
     const int tab_bytes = D * C * 2;
     char *tk = smem, *tv = smem + tab_bytes;
-    char *tile = smem + 2 * tab_bytes + wave * kTile;
-    float *part = (float *)(smem + 2 * tab_bytes + kTW * kTile);
+    char *tile = smem + wave * kTile;          // residual workgroup only (it loads no codebook)
+    int region = 2 * tab_bytes;
+    if (kTW * kTile > region) region = kTW * kTile;
+    if (kTW * (G * D + 2 * G) * 4 > region) region = kTW * (G * D + 2 * G) * 4;
+    region = (region + 15) / 16 * 16;
+    float *part = (float *)(smem + region);
     int *flag = (int *)(part + p.slot_floats);
 
     const bool is_resid = slot == p.nsplit;
@@ -100,14 +115,15 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
     if (!is_resid && n_tiles > 0) {
         for (int i = tid * 16; i < tab_bytes; i += kTW * 64 * 16) {
             *(t4u *)(tk + i) = *(const t4u *)((const char *)p.k_tab + i);
-            *(t4u *)(tv + i) = *(const t4u *)((const char *)p.v_tab + i);
+            *(t4u *)(tv + i) = *(const t4u *)((const char *)p.v_tab_col + i);      // col image [c][m][d_m]: bank = subspace
         }
     }
     t8f16 qb[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         t4u z = {0u, 0u, 0u, 0u};
-        if (c16 < G) z = *(const t4u *)(p.q + ((long long)b * p.nh + head0(p, hk) + c16) * D + 32 * s + 8 * q4);
+        // stage s of lane quarter q4 = dims q4 * D/4 + 8 s .. + 8: the dims of the lane's own code bytes (direct gathers)
+        if (c16 < G) z = *(const t4u *)(p.q + ((long long)b * p.nh + head0(p, hk) + c16) * D + q4 * (D / 4) + 8 * s);
         qb[s] = __builtin_bit_cast(t8f16, z);
     }
     __syncthreads();
@@ -117,14 +133,17 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
 #pragma unroll
     for (int n = 0; n < NC; ++n) O[n] = t4f32{0.f, 0.f, 0.f, 0.f};
 
-    // ---- steps 2-3: scores of the K^ tile, online softmax; returns the probabilities (B operand of step 5) ----
-    auto scores = [&](int n_valid) -> t4f16 {
+    // ---- residual window: scores of the K^ tile in LDS ----
+    auto scores_lds = [&]() -> t4f32 {
         t4f32 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const t4u a = *(const t4u *)(tile + c16 * kKRow + (32 * s + 8 * q4) * 2);
+            const t4u a = *(const t4u *)(tile + c16 * kKRow + (q4 * (D / 4) + 8 * s) * 2);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t8f16, a), qb[s], acc, 0, 0, 0);
         }
+        return acc;
+    };
+    auto softmax_tile = [&](t4f32 acc, int n_valid) -> t4f16 {
         float sc[4], mx = -INFINITY;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {          // acc[v] = S[token 4*q4 + v][head c16]
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
         // ================= code tiles =================
         const int tl = c16, mq = q4;           // step 1 lane roles: token, quarter of the code row
         const int ps_mask = p.page_size - 1;
-        struct Codes { unsigned k[KD]; unsigned v[NTASK][VR][2]; };
+        struct Codes { unsigned k[KD]; unsigned v[CG]; };      // K: the lane's quarter of its token's code row; V: 4 tokens of subspace 16 cg + c16
         struct Pids { long long k, v; };
         auto tile_t0 = [&](int j) {            // first token of this wave's j-th tile (clamped: re-request, never past the split)
             int ti = wave + kTW * j;
@@ -217,71 +236,80 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
             if constexpr (KD == 1) c.k[0] = *(const unsigned *)krow;
             else if constexpr (KD == 2) { const v2u w = *(const v2u *)krow; c.k[0] = w[0]; c.k[1] = w[1]; }
             else { const t4u w = *(const t4u *)krow; c.k[0] = w[0]; c.k[1] = w[1]; c.k[2] = w[2]; c.k[3] = w[3]; }
+            // V: a tile never straddles a page (16 | page_size); bytes of tokens >= T inside the page are whatever the page
+            // holds: "& (C - 1)" keeps them inside the table and their probabilities are exact zeros
 #pragma unroll
-            for (int j = 0; j < NTASK; ++j) {
-                const int task = j * 64 + lane, dp = task >> 1, oct = task & 1;
-                const int m0 = (2 * dp) / DM;
-#pragma unroll
-                for (int rr = 0; rr < VR; ++rr) {
-                    const v2u w = *(const v2u *)(p.v_codes + ((id.v * M + m0 + rr) << p.ps_shift) + (t0 & ps_mask) + 8 * oct);
-                    c.v[j][rr][0] = w[0]; c.v[j][rr][1] = w[1];
-                }
-            }
+            for (int cg = 0; cg < CG; ++cg)
+                c.v[cg] = *(const unsigned *)(p.v_codes + ((id.v * M + 16 * cg + c16) << p.ps_shift) + (t0 & ps_mask) + 4 * q4);
             return c;
         };
-        // Lookup addresses: one v_bfe_u32 + one v_lshl_add_u32 per code byte.  The per-subspace table bases are
-        // lane constants kept in registers, and the "& (C - 1)" that keeps a stray byte inside its table row is applied
-        // to four bytes at once.
+        // Lookup addresses: one v_bfe_u32 + one v_lshl_add_u32 per code byte.  The per-subspace table bases are lane
+        // constants kept in registers, and the "& (C - 1)" that keeps a stray byte inside its table row is applied to four
+        // bytes at once.
         constexpr unsigned kEsh = DM == 8 ? 4 : DM == 4 ? 3 : DM == 2 ? 2 : 1;      // log2(bytes per codebook entry)
+        constexpr unsigned kVsh = D == 128 ? 8 : 7;                                  // log2(bytes per code of the V col image = 2 d)
         const unsigned cm4 = cmask * 0x01010101u;
         const char *kb[M / 4];
 #pragma unroll
         for (int j = 0; j < M / 4; ++j) kb[j] = tk + (mq * (M / 4) + j) * C * (DM * 2);
-        const char *vb[NTASK][VR];
+        const char *vb[CG];
 #pragma unroll
-        for (int j = 0; j < NTASK; ++j) {
-            const int dp = (j * 64 + lane) >> 1;
+        for (int cg = 0; cg < CG; ++cg) vb[cg] = tv + (16 * cg + c16) * (DM * 2);
+        auto code_of = [&](unsigned w, int i) -> unsigned { return ((w & cm4) >> (8 * (i & 3))) & 0xffu; };
+        // ---- step 1: scores straight from the K row image ----
+        auto scores_direct = [&](const Codes &c) -> t4f32 {
+            t4f32 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rr = 0; rr < VR; ++rr)
-                vb[j][rr] = DM == 1 ? tv + (2 * dp + rr) * C * 2 : tv + (((2 * dp) / DM) * C * DM + (2 * dp) % DM) * 2;
-        }
-        auto fill_k = [&](const Codes &c) {
-            unsigned buf[D / 8];               // this lane's d/4 dims of its token
+            for (int st = 0; st < NS; ++st) {
+                t4u a;
+                if constexpr (DM == 8) {
+                    a = *(const t4u *)(kb[st] + (code_of(c.k[st >> 2], st) << kEsh));
+                } else if constexpr (DM == 4) {
+                    const v2u x = *(const v2u *)(kb[2 * st] + (code_of(c.k[(2 * st) >> 2], 2 * st) << kEsh));
+                    const v2u y = *(const v2u *)(kb[2 * st + 1] + (code_of(c.k[(2 * st + 1) >> 2], 2 * st + 1) << kEsh));
+                    a = t4u{x[0], x[1], y[0], y[1]};
+                } else if constexpr (DM == 2) {
 #pragma unroll
-            for (int j = 0; j < M / 4; ++j) {
-                const unsigned code = ((c.k[j >> 2] & cm4) >> (8 * (j & 3))) & 0xffu;
-                const char *e = kb[j] + (code << kEsh);
-                if constexpr (DM == 8) { const t4u x = *(const t4u *)e; buf[4 * j] = x[0]; buf[4 * j + 1] = x[1]; buf[4 * j + 2] = x[2]; buf[4 * j + 3] = x[3]; }
-                else if constexpr (DM == 4) { const v2u x = *(const v2u *)e; buf[2 * j] = x[0]; buf[2 * j + 1] = x[1]; }
-                else if constexpr (DM == 2) buf[j] = *(const unsigned *)e;
-                else {
-                    const unsigned x = *(const unsigned short *)e;
-                    if (j & 1) buf[j >> 1] |= x << 16; else buf[j >> 1] = x;
-                }
-            }
-            char *dst = tile + tl * kKRow + mq * (D / 2);
+                    for (int i = 0; i < 4; ++i) a[i] = *(const unsigned *)(kb[4 * st + i] + (code_of(c.k[(4 * st + i) >> 2], 4 * st + i) << kEsh));
+                } else {
 #pragma unroll
-            for (int i = 0; i < D / 32; ++i) *(t4u *)(dst + 16 * i) = t4u{buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]};
-        };
-        auto fill_v = [&](const Codes &c) {
-#pragma unroll
-            for (int j = 0; j < NTASK; ++j) {
-                const int task = j * 64 + lane, dp = task >> 1, oct = task & 1;
-                unsigned e[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const unsigned c0 = ((c.v[j][0][t >> 2] & cm4) >> (8 * (t & 3))) & 0xffu;
-                    if constexpr (DM == 1) {
-                        const unsigned c1 = ((c.v[j][1][t >> 2] & cm4) >> (8 * (t & 3))) & 0xffu;
-                        const unsigned x0 = *(const unsigned short *)(vb[j][0] + (c0 << 1));
-                        const unsigned x1 = *(const unsigned short *)(vb[j][1] + (c1 << 1));
-                        e[t] = x0 | (x1 << 16);
-                    } else {
-                        e[t] = *(const unsigned *)(vb[j][0] + (c0 << kEsh));
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned lo = *(const unsigned short *)(kb[8 * st + 2 * i] + (code_of(c.k[(8 * st + 2 * i) >> 2], 8 * st + 2 * i) << kEsh));
+                        const unsigned hi = *(const unsigned short *)(kb[8 * st + 2 * i + 1] + (code_of(c.k[(8 * st + 2 * i + 1) >> 2], 8 * st + 2 * i + 1) << kEsh));
+                        a[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
                     }
                 }
-                store_vt(dp, oct, e);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t8f16, a), qb[st], acc, 0, 0, 0);
             }
+            return acc;
+        };
+        // ---- step 3: the V entries of this lane's 4 tokens x CG subspaces (independent of the softmax: issued with the K gathers) ----
+        struct VEnt { unsigned e[CG][4][EW]; };
+        auto gather_v = [&](const Codes &c) -> VEnt {
+            VEnt v;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const char *ep = vb[cg] + (code_of(c.v[cg], t) << kVsh);
+                    if constexpr (DM == 8) { const t4u x = *(const t4u *)ep; v.e[cg][t][0] = x[0]; v.e[cg][t][1] = x[1]; v.e[cg][t][2] = x[2]; v.e[cg][t][3] = x[3]; }
+                    else if constexpr (DM == 4) { const v2u x = *(const v2u *)ep; v.e[cg][t][0] = x[0]; v.e[cg][t][1] = x[1]; }
+                    else if constexpr (DM == 2) v.e[cg][t][0] = *(const unsigned *)ep;
+                    else v.e[cg][t][0] = *(const unsigned short *)ep;
+                }
+            return v;
+        };
+        // ---- step 4: O^T tile (cg, e) += V^T_e (rows = subspaces 16 cg + .., k = 16 tokens) P ----
+        auto values_direct = [&](const VEnt &v, t4f16 P) {
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+                for (int e = 0; e < DM; ++e) {
+                    const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const v2u a = {__builtin_amdgcn_perm(v.e[cg][1][e >> 1], v.e[cg][0][e >> 1], sel),
+                                   __builtin_amdgcn_perm(v.e[cg][3][e >> 1], v.e[cg][2][e >> 1], sel)};
+                    O[cg * DM + e] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(t4f16, a), P, O[cg * DM + e], 0, 0, 0);
+                }
         };
 
         if (n_tiles > 0) {
@@ -289,7 +317,7 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
             // Code bytes kPF tiles ahead, page ids 2 kPF tiles ahead, in a register ring with compile-time slots (the loop
             // is unrolled by the ring size; a tile is 5-9 registers).  One tile ahead is not enough: an iteration is
             // ~0.6 us of work and a load under traffic takes 1-2 us, so the loop ran at the load latency.
-            constexpr int kPF = TW == 4 ? 4 : 2;       // (sixteen waves per CU hide latency by themselves; <= 128 VGPRs)
+            constexpr int kPF = TW <= 8 ? 4 : 2;       // (sixteen waves per CU hide latency by themselves; <= 128 VGPRs)
             Codes ring[kPF];
             Pids idr[kPF];
 #pragma unroll
@@ -309,17 +337,13 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
                     if (j < my_tiles) {                                   // wave-uniform; no global load inside
                         const int t0 = tile_t0(j);
                         TILE_PROF_T(0);
-                        fill_k(cur);
-                        lds_phase();
+                        const t4f32 acc = scores_direct(cur);
+                        const VEnt ve = gather_v(cur);
                         TILE_PROF_T(1);
-                        const t4f16 P = scores(min(kTT, t_end - t0));
-                        lds_phase();
+                        const t4f16 P = softmax_tile(acc, min(kTT, t_end - t0));
                         TILE_PROF_T(2);
-                        fill_v(cur);
-                        lds_phase();
+                        values_direct(ve, P);
                         TILE_PROF_T(3);
-                        values(P);
-                        lds_phase();
                         TILE_PROF_T(4);
                         TILE_PROF_ACC();
                     }
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
                 for (int i = 0; i < D / 32; ++i) *(t4u *)(dst + 16 * i) = *(const t4u *)((const char *)src + 16 * i);
             }
             lds_phase();
-            const t4f16 P = scores(min(kTT, t_end - t0));
+            const t4f16 P = softmax_tile(scores_lds(), min(kTT, t_end - t0));
             lds_phase();
 #pragma unroll
             for (int j = 0; j < NTASK; ++j) {
@@ -373,16 +397,21 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
     {
         const int wf = G * D + 2 * G;                         // floats per wave
         const float l_sum = rows_sum(l_run);
-        float *ws = (float *)(smem + 2 * tab_bytes) + wave * wf;
+        float *ws = (float *)smem + wave * wf;                 // the codebooks / wave tiles are dead (barrier above)
         if (c16 < G) {
 #pragma unroll
             for (int n = 0; n < NC; ++n)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) ws[c16 * D + 16 * n + 4 * q4 + v] = O[n][v];
+                for (int v = 0; v < 4; ++v) {
+                    // code workgroups: tile n = (column group n / d_m, dim e = n % d_m), row = subspace 16 cg + 4 q4 + v;
+                    // residual workgroup: tile n = dims 16 n .. 16 n + 15
+                    const int dim = is_resid ? 16 * n + 4 * q4 + v : (16 * (n / DM) + 4 * q4 + v) * DM + n % DM;
+                    ws[c16 * D + dim] = O[n][v];
+                }
             if (q4 == 0) { ws[G * D + c16] = m_run; ws[G * D + G + c16] = l_sum; }
         }
         __syncthreads();
-        const float *w0 = (const float *)(smem + 2 * tab_bytes);
+        const float *w0 = (const float *)smem;
         for (int e = tid; e < wf; e += kTW * 64) {            // e: O[g][dim], then m[g], then l[g]
             const int g = e < G * D ? e / D : (e - G * D) % G;
             float mm = -INFINITY;
@@ -399,14 +428,15 @@ __global__ __launch_bounds__(TW * 64, TW == 4 ? 2 : 1) void attn_tile_kernel(Att
         }
         __syncthreads();
     }
-    publish_and_merge(p, b, hk, slot, part, (float *)smem, flag);      // the codebooks are dead: merge scratch
+    // merge scratch of the last arriver: the waves' partials above are dead once `part` is complete (barrier above)
+    publish_and_merge(p, b, hk, slot, part, (float *)smem, flag);
 }
 
 bool attn_tile_supported(const AttnParams &p) {
     const bool shape = (p.d == 128 || p.d == 64) && (p.M == 16 || p.M == 32 || p.M == 64) && (p.C == 128 || p.C == 256) &&
-                       p.G <= kMaxG;
+                       p.G <= kMaxGMfma;      // the 16 columns of the score tile: up to 16 query heads per kv head and launch (round 4)
     if (!shape || !p.v_paged) return false;
-    return tile_lds_bytes(p.d, p.C, p.slot_floats, 4) <= 160 * 1024;
+    return tile_lds_bytes(p.d, p.C, p.slot_floats, 16, p.G) <= 160 * 1024;
 }
 bool attn_tile_shape_ok(const AttnParams &p) {
     AttnParams q = p;
@@ -416,15 +446,15 @@ bool attn_tile_shape_ok(const AttnParams &p) {
 
 int launch_attn_tile(const AttnParams &p_in, hipStream_t s) {
     AttnParams p = p_in;
-    // d = 64: sixteen waves in one workgroup per CU while a CU has at most 128 tiles to walk, else two 4-wave workgroups
+    // Waves per workgroup (round 4: a code tile needs no LDS of its own any more, so the codebooks alone decide how many
+    // workgroups fit - one per CU at d = 128 - and the registers how many waves: 16 where the kernel stays within 128
+    // registers (d = 64; d = 128 with 16-byte entries), 8 otherwise).  More waves = fewer 16-token tiles per wave and more
+    // LDS round trips in flight.
     const int bh = p.bs * p.nh_k;
     const int cus = device_cus();
-    const bool wide = p.d == 64 && (long long)p.T * bh <= 128ll * kTT * cus;
-    const int waves = wide ? 16 : 4;
-    // split policy: one workgroup per CU (two of the 4-wave ones at d = 64); a split is a multiple of 64 tokens and at
-    // least 256 tokens long
-    const int target = cus * (p.d == 64 && !wide ? 2 : 1);
-    int ns = (target + bh - 1) / bh;
+    const int waves = (p.d == 64 || p.dm == 8) ? 16 : 8;
+    // split policy: one workgroup per CU; a split is a multiple of 64 tokens and at least 256 tokens long
+    int ns = (cus + bh - 1) / bh;
     if (ns > kMaxSplits) ns = kMaxSplits;
     int by_len = (p.T + 255) / 256;
     if (by_len < 1) by_len = 1;
@@ -436,11 +466,10 @@ int launch_attn_tile(const AttnParams &p_in, hipStream_t s) {
     p.nsplit = ns;
     p.split_len = len;
     p.nslots = ns + 1;
-    const size_t lds = tile_lds_bytes(p.d, p.C, p.slot_floats, waves);
+    const size_t lds = tile_lds_bytes(p.d, p.C, p.slot_floats, waves, p.G);
     if (device_once(2)) {
 #define TILE_ATTR(D_, DM_, TW_) (void)hipFuncSetAttribute((const void *)attn_tile_kernel<D_, DM_, TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        TILE_ATTR(128, 8, 4); TILE_ATTR(128, 4, 4); TILE_ATTR(128, 2, 4);
-        TILE_ATTR(64, 4, 4); TILE_ATTR(64, 2, 4); TILE_ATTR(64, 1, 4);
+        TILE_ATTR(128, 8, 16); TILE_ATTR(128, 4, 8); TILE_ATTR(128, 2, 8);
         TILE_ATTR(64, 4, 16); TILE_ATTR(64, 2, 16); TILE_ATTR(64, 1, 16);
 #undef TILE_ATTR
     }
@@ -448,12 +477,12 @@ int launch_attn_tile(const AttnParams &p_in, hipStream_t s) {
 #define TILE_LAUNCH(D_, DM_, TW_) hipLaunchKernelGGL((attn_tile_kernel<D_, DM_, TW_>), grid, block, lds, s, p)
     const int key = p.d * 16 + p.dm;
     switch (key) {
-    case 128 * 16 + 8: TILE_LAUNCH(128, 8, 4); break;
-    case 128 * 16 + 4: TILE_LAUNCH(128, 4, 4); break;
-    case 128 * 16 + 2: TILE_LAUNCH(128, 2, 4); break;
-    case 64 * 16 + 4: if (wide) TILE_LAUNCH(64, 4, 16); else TILE_LAUNCH(64, 4, 4); break;
-    case 64 * 16 + 2: if (wide) TILE_LAUNCH(64, 2, 16); else TILE_LAUNCH(64, 2, 4); break;
-    case 64 * 16 + 1: if (wide) TILE_LAUNCH(64, 1, 16); else TILE_LAUNCH(64, 1, 4); break;
+    case 128 * 16 + 8: TILE_LAUNCH(128, 8, 16); break;
+    case 128 * 16 + 4: TILE_LAUNCH(128, 4, 8); break;
+    case 128 * 16 + 2: TILE_LAUNCH(128, 2, 8); break;
+    case 64 * 16 + 4: TILE_LAUNCH(64, 4, 16); break;
+    case 64 * 16 + 2: TILE_LAUNCH(64, 2, 16); break;
+    case 64 * 16 + 1: TILE_LAUNCH(64, 1, 16); break;
     default: set_error("attn_tile: d=%d d_m=%d", p.d, p.dm); return MILLION_ERR_SHAPE;
     }
 #undef TILE_LAUNCH

@@ -405,6 +405,7 @@ bool attn_mfma_shape_ok(const AttnParams &p);
 int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hipStream_t s);
 bool attn_mfma_supported(const AttnParams &p);
 bool attn_mfma_handles(const AttnParams &p);     // supported AND launch_attn_mfma will not hand the call back (kAttnNotHandled)
+bool attn_mfma_streams(const AttnParams &p);     // ... and the streaming kernel runs (not the grouped one: T = 0, > 1M tokens)
 void set_error(const char *fmt, ...);
 
 // Per-device facts and one-time per-device setup (one process may drive several devices): CU count, and a set of

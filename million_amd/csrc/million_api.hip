@@ -396,13 +396,13 @@ int million_attn_kernel_kind(const million_attn_desc *desc) {
     AttnParams p;
     if (fill_attn_params(desc, p) != MILLION_OK) return -1;
     if (g_force_generic) return 0;
-    if (attn_mfma_supported(p) && attn_mfma_handles(p)) return 1;
+    if (attn_mfma_supported(p) && attn_mfma_handles(p)) return attn_mfma_streams(p) ? 1 : 5;
     if (attn_mfma_shape_ok(p) && !p.v_paged && !p.k_paged && p.T > 0) {               // transpose + MFMA kernel
         AttnParams pt = p;
         pt.v_paged = 1; pt.v_identity = 1; pt.page_size = 64; pt.ps_shift = 6;
-        if (attn_mfma_handles(pt)) return 2;
+        if (attn_mfma_handles(pt)) return attn_mfma_streams(pt) ? 2 : 5;
     }
-    const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxG ? p.Gt : kMaxG);              // tile kernel: kMaxG heads per launch
+    const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxGMfma ? p.Gt : kMaxGMfma);      // tile kernel: up to kMaxGMfma heads per launch
     if (attn_tile_supported(p8)) return 3;                                            // tile kernel
     if (attn_tile_shape_ok(p8) && !p.v_paged && !p.k_paged) return 4;                 // transpose + tile kernel
     return 0;
@@ -418,6 +418,7 @@ static int launch_group(const AttnParams &p, hipStream_t stream) {
             if (rc_fast != kAttnNotHandled) return rc_fast;
         }
     }
+    if (!g_force_generic && attn_tile_supported(p)) return launch_attn_tile(p, stream);      // up to kMaxGMfma heads per launch
     if (p.G > kMaxG) {
         for (int g1 = 0; g1 < p.G; g1 += kMaxG) {
             AttnParams h = with_heads(p, p.g0 + g1, p.G - g1 < kMaxG ? p.G - g1 : kMaxG);
@@ -496,7 +497,7 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     // The fast kernels want V in transposed pages: the reference's 10-arg row-major layout is transposed into scratch
     // pages first (once per call, whatever the number of query-head groups below).
     AttnParams pl = p;
-    const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxG ? p.Gt : kMaxG);
+    const AttnParams p8 = with_heads(p, 0, p.Gt < kMaxGMfma ? p.Gt : kMaxGMfma);
     if (!g_force_generic && !p.v_paged && !p.k_paged && (attn_mfma_shape_ok(p) || attn_tile_shape_ok(p8))) {
         pl.v_paged = 1; pl.v_identity = 1; pl.page_size = 64; pl.ps_shift = 6;
         pl.n_pages_cap = p.T > 0 ? (p.T + 63) / 64 : 1;
@@ -513,7 +514,8 @@ static int attn_impl(const million_attn_desc *desc, const void *q, const void *k
     // nh / nh_k = 16 reads its codes once), of the other kernels up to 8; bigger groups run as several launches on the same
     // stream and workspace, each re-reading the codes.  A fused append happens in the first one: the later ones find the
     // row in the window.
-    const int step = (!g_force_generic && attn_mfma_supported(pl)) ? kMaxGMfma : kMaxG;
+    const AttnParams p16 = with_heads(pl, 0, p.Gt < kMaxGMfma ? p.Gt : kMaxGMfma);
+    const int step = (!g_force_generic && (attn_mfma_supported(pl) || attn_tile_supported(p16))) ? kMaxGMfma : kMaxG;
     for (int g0 = 0; g0 < p.Gt; g0 += step) {
         AttnParams pg = with_heads(pl, g0, p.Gt - g0 < step ? p.Gt - g0 : step);
         if (g0 > 0) after_first_launch(pg);

@@ -1427,16 +1427,37 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
 
 def test_attn_kernel_kind_mirrors_the_hand_back(env, oracle):
     """million_attn_kernel_kind answers what a call WOULD run: d = 128 / M = 64 / C = 128 is the streaming kernel's shape, but
-    with nothing quantised yet (T = 0) launch_attn_mfma hands the call to the tile kernel (kind 3), as it does for more
-    than 64 rounds per wave; C = 256 keeps the grouped MFMA kernel for those (kind 1)."""
+    with nothing quantised yet (T = 0) launch_attn_mfma hands the call to the tile kernel (kind 3); C = 256 keeps the grouped
+    MFMA kernel for that (kind 5)."""
     torch, ops = env
     c = synth.attn_case(7700, 1, 8, 2, 128, 64, 128, 0, 40, Lt=128)
     t = _dev(torch, c)
     kw = dict(nh_k=2, M=64, r=40, k_paged=True, v_paged=True, page_size=64)
     assert _kind(torch, ops, t["q"], t["k_res"], C=128, n_tokens=0, n_pages_cap=1, **kw) == 3
     assert _kind(torch, ops, t["q"], t["k_res"], C=128, n_tokens=4096, n_pages_cap=64, **kw) == 1
-    assert _kind(torch, ops, t["q"], t["k_res"], C=256, n_tokens=0, n_pages_cap=1, **kw) == 1
+    assert _kind(torch, ops, t["q"], t["k_res"], C=256, n_tokens=0, n_pages_cap=1, **kw) == 5      # grouped MFMA kernel (no code units)
     _check(_run_rowmajor(torch, ops, c, 64, 128), oracle.decode_attn(**c), "C=128 T=0 (tile kernel)")
+
+
+@pytest.mark.parametrize("bs,nh,nhk,T,C,r", [(16, 32, 8, 40000, 256, 100), (8, 32, 32, 32768, 256, 17), (32, 32, 8, 20000, 128, 128)],
+                         ids=["16x8-pairs-40K", "8x32-pairs-32K", "32x8-pairs-20K-C128"])
+def test_attn_many_pairs_long_context_stay_on_streaming_kernel(bs, nh, nhk, T, C, r, env, oracle):
+    """More than 64 rounds per wave at the default split count (bs * nh_k >= 128 with T > 32768, >= 256 with T > 16384): rounds
+    2-3 dropped these calls to the grouped kernel, and C = 128 to the scalar one.  They now get more
+    splits - more workgroups than CUs - and stay on the streaming kernel, like the reference's one kernel for any (bs, nh, T)
+    (Interface.template.cu:45,62-77)."""
+    torch, ops = env
+    from million_amd import _lib
+    ps, M = 64, 64
+    c = synth.attn_case(9900 + bs + T % 17, bs, nh, nhk, 128, M, C, T, r)
+    gold = oracle.decode_attn(**c)
+    t = _dev(torch, c)
+    desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
+                              page_size=ps, n_pages_cap=(T + ps - 1) // ps)
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1      # streaming, not grouped (5) / scalar (0)
+    _lib.load().million_debug_tail_faults()
+    _check(_run_paged(torch, ops, oracle, c, M, C, ps), gold, f"bs={bs} nh_k={nhk} T={T} C={C}")
+    assert _lib.load().million_debug_tail_faults() == 0
 
 
 @pytest.mark.parametrize("d,M", [(64, 32), (128, 16), (64, 64)], ids=["d64M32", "d128M16", "d64M64"])
@@ -1790,6 +1811,25 @@ def _sdpa_ref_rows(q, k, v, rows, q_pos0=0, causal=True):
     return out
 
 
+def _sdpa_ref_rows_at(qs, k, v, rows):
+    """The same for query rows that were sliced out already: qs (bs, nh, len(rows), d) are the rows `rows` of a long causal
+    prompt (the full q of a 128K prompt is 1 GB: only the sampled rows leave the GPU)."""
+    bs, nh, _, d = qs.shape
+    nhk, n_kv = k.shape[1], k.shape[2]
+    G = nh // nhk
+    out = np.zeros((bs, nh, len(rows), d))
+    for b in range(bs):
+        for hk in range(nhk):
+            kf, vf = k[b, hk].astype(np.float64), v[b, hk].astype(np.float64)
+            for h in range(hk * G, (hk + 1) * G):
+                s = qs[b, h].astype(np.float64) @ kf.T / np.sqrt(d)
+                s = np.where(np.arange(n_kv)[None, :] <= np.asarray(rows)[:, None], s, -np.inf)
+                s = s - s.max(axis=1, keepdims=True)
+                pr = np.exp(s)
+                out[b, h] = (pr / pr.sum(axis=1, keepdims=True)) @ vf
+    return out
+
+
 @pytest.mark.parametrize("bs,nh,nhk,n_q,n_kv,q_pos0,causal", [
     (1, 8, 2, 1, 1, 0, True), (1, 8, 2, 33, 33, 0, True), (2, 4, 4, 100, 100, 0, True), (1, 6, 2, 257, 257, 0, True),
     (1, 8, 1, 300, 300, 0, True), (1, 16, 8, 130, 130, 0, True), (1, 8, 2, 64, 200, 136, True), (1, 8, 2, 70, 333, 0, False),
@@ -1877,6 +1917,26 @@ def test_prefill_attn_32k_sampled_rows(env):
     rows = [0, 1, 63, 64, 65, 4095, 4096, 20000, 32703, 32704, 32767]
     gold = _sdpa_ref_rows(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), rows)
     _check(out[:, :, rows].cpu().numpy(), gold, "prefill 32k sampled rows")
+
+
+def test_prefill_attn_128k_sampled_rows(env):
+    """BASELINE configs[4]'s prompt length: (1, 32, 8, 131072, 128) - 4 x the rows of the 32K test, so the row / tile / key-tile
+    index arithmetic of prefill.hip (t * kKV, pf_off, kv_end_wg) runs at the size the bench times it at.  First row, last
+    row and rows at tile edges of every head against the fp64 reference (pq_utils.py:249-260: causal SDPA of the prompt)."""
+    torch, ops = env
+    n = 131072
+    g = torch.Generator(device="cuda").manual_seed(6)
+    q = torch.randn(1, 32, n, 128, generator=g, device="cuda").half()
+    k = torch.randn(1, 8, n, 128, generator=g, device="cuda").half()
+    v = torch.randn(1, 8, n, 128, generator=g, device="cuda").half()
+    out = ops.prefill_attn(q, k, v)
+    torch.cuda.synchronize()
+    rows = [0, 63, 64, 255, 256, 65535, 65536, 100001, n - 257, n - 256, n - 1]
+    qs = q[:, :, rows].cpu().numpy()
+    gold = _sdpa_ref_rows_at(qs, k.cpu().numpy(), v.cpu().numpy(), rows)
+    _check(out[:, :, rows].cpu().numpy(), gold, "prefill 128k sampled rows")
+    del q, k, v, out
+    torch.cuda.empty_cache()
 
 
 def test_paged_cache_prefill_uses_hip_attention(env, oracle):

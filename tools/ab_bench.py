@@ -17,6 +17,7 @@ ap.add_argument("--cfg", nargs="*", default=["1,32768,64", "2,32768,64", "4,3276
 ap.add_argument("--layers", type=int, default=32)
 ap.add_argument("--nh", type=int, default=32)
 ap.add_argument("--nh-k", type=int, default=8)
+ap.add_argument("--C", type=int, default=256)
 ap.add_argument("--shuffle-pages", action="store_true", help="random page permutation (default: ids in allocation order, as PagedPQCache hands them out)")
 ap.add_argument("--iters", type=int, default=96)
 ap.add_argument("--dev-lengths", action="store_true")
@@ -36,13 +37,13 @@ for cfg in args.cfg:
     f = [int(x) for x in cfg.split(",")]
     bs, T, M = f[:3]
     d = f[3] if len(f) > 3 else 128
-    nh, nhk, C, ps, r = args.nh, args.nh_k, 256, 64, 100
+    nh, nhk, C, ps, r = args.nh, args.nh_k, args.C, 64, 100
     n_pages = (T + ps - 1) // ps
     states = []
     nl = max(4, min(args.layers, int(6e9 // (2 * bs * nhk * n_pages * ps * M))))      # keep the pools under ~6 GB
     for l in range(nl):
-        kpool = torch.randint(0, 256, (bs * nhk * n_pages, ps, M), dtype=torch.uint8, device=dev)
-        vpool = torch.randint(0, 256, (bs * nhk * n_pages, M, ps), dtype=torch.uint8, device=dev)
+        kpool = torch.randint(0, C, (bs * nhk * n_pages, ps, M), dtype=torch.uint8, device=dev)
+        vpool = torch.randint(0, C, (bs * nhk * n_pages, M, ps), dtype=torch.uint8, device=dev)
         ids = (torch.randperm(bs * nhk * n_pages, device=dev) if args.shuffle_pages else torch.arange(bs * nhk * n_pages, device=dev)).to(torch.int32).reshape(bs, nhk, n_pages)
         if args.zero_codes:
             kpool.zero_(); vpool.zero_()
@@ -117,6 +118,7 @@ for cfg in args.cfg:
                 best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
         return best
 
+    kind = lib.million_attn_kernel_kind(__import__('ctypes').byref(ops.make_attn_desc(q, kr, nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True, page_size=ps, n_pages_cap=n_pages)))
     best = timed(args.iters)
     scalar = None
     if args.vs_scalar:
@@ -127,6 +129,6 @@ for cfg in args.cfg:
     if args.bindings_10arg:
         tag = tag + " 10-arg"
     extra = f"   scalar fallback {scalar:8.1f} us ({scalar / best:5.1f}x)" if scalar else ""
-    print(f"{tag:34s} bs={bs} T={T:6d} d={d} M={M}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs cross-check {err:.1e}{extra}", flush=True)
+    print(f"{tag:34s} bs={bs} nh={nh} nh_k={nhk} T={T:6d} d={d} M={M} C={C} kind={kind}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs cross-check {err:.1e}{extra}", flush=True)
     del states
     torch.cuda.empty_cache()
