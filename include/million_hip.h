@@ -235,7 +235,8 @@ int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh
  * (anything else the descriptor allows: C not 128 / 256, paged K with row-major V, ...), -1 = bad descriptor. */
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Kernel choice for A/B measurements and tests: 0 = auto (default), 1 = generic kernel only, 2 = MFMA grouped kernel
- * only (never the streaming one). */
+ * only (never the streaming one), 4 = auto, but the helper workgroups of the split merge give up at once (exercises the
+ * last arriver's take-over path of the MFMA kernels' tail). */
 void million_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------

@@ -704,11 +704,11 @@ __device__ unsigned g_tail_faults = 0;
 
 // One query head is merged by FOUR waves: wave part (0..3) owns outputs [32 part, 32 part + 32) of the head; its lane
 // (h, q8) owns float4 q8 of those for the splits s = h (mod 8): ns / 8 16-byte loads per lane, the eight split subsets are
-// summed with DPP / row swaps.  NJ = 2 merges heads g and g + 2 in one pass: every load of both heads is issued before the
+// summed with DPP / row swaps.  NJ = 2 merges heads g and g + gstep in one pass: every load of both heads is issued before the
 // first reduction (one memory round trip for the pair; round 4: the ONE merging workgroup serves all heads, see
 // merge_and_publish).  `second` is wave-uniform: false = only head g.
 template <int NJ>
-__device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int hk, int g, int part, int ns, const float *src,
+__device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int hk, int g, int gstep, int part, int ns, const float *src,
                                                  int lane, bool second, bool fault) {
     const int q8 = lane & 7, h = lane >> 3;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
@@ -719,7 +719,7 @@ __device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int
     v4u v[NJ][8];
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
-        const int gj = (jj == 0 || second) ? g + 2 * jj : g;      // a missing second head re-reads the first (never a conditional load)
+        const int gj = (jj == 0 || second) ? g + gstep * jj : g;      // a missing second head re-reads the first (never a conditional load)
         m1[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + gj) * 4, 0, 16));
         l1[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + gj) * 4, 0, 16));
 #pragma unroll
@@ -759,7 +759,7 @@ __device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int
         if (lane < 8) {
             typedef f16 h4 __attribute__((ext_vector_type(4)));
             const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-            *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g + 2 * jj) * 128 + 32 * part + 4 * q8) = o;
+            *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g + gstep * jj) * 128 + 32 * part + 4 * q8) = o;
         }
     }
 }
@@ -892,32 +892,69 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     }
     if (p.dbg && tid == 0)      // diagnostics: slot 12 = 1 + "stored plain (every split on this XCD)", slot 13 = 1 + arrival index
         { unsigned long long *d_ = p.dbg + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kStampWaves * kStampSlots; d_[12] = 1 + (same_xcd ? 1 : 0); d_[13] = 1 + idx; }
-    // ---- the merge: the workgroup whose arrival index is ns - 1, and nobody else (round 4).  Every workgroup it waits for
-    //      has taken its index, i.e. is resident and on its way to its own flag store, and waits for nothing itself: the polls
-    //      end under ANY dispatch order and residency.  (Round 3 let the nm = min(G, ns) highest indices merge one head each:
-    //      a merger other than the last arriver then polls flags of workgroups that may not have been DISPATCHED - with more
-    //      workgroups than resident slots, or two launches sharing the chip, every resident workgroup can be such a merger and
-    //      the launch stalls until the spin bound, then merges stale partials.  The single merger costs the pair one more
-    //      batch of loads, not a second round trip: tail_merge_heads<2>.)
-    //      Four waves per head: waves 0-3 heads 0, 2 | 4, 6 | ..., waves 4-7 heads 1, 3 | 5, 7 | ...; every merging wave polls
-    //      the flags itself (lane = split): its loads follow its own match. ----
-    if (idx == ns - 1 && ns > 1) {
-        bool fault = false;
-        {
-            __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
+    // ---- the merge (round 4).  The workgroup whose arrival index is ns - 1 - the PRIMARY - is responsible for every head:
+    //      every workgroup it waits for has taken its index, i.e. is resident, on its way to its own flag store, and waits
+    //      for nothing itself, so its polls end under ANY dispatch order and residency.  The nm - 1 workgroups that arrived
+    //      just before it are HELPERS (merger k = idx - (ns - nm) takes heads k, k + nm, ...): a helper needs flags of
+    //      workgroups that arrived AFTER it and may not even be dispatched (more workgroups than resident slots; two launches
+    //      sharing the chip), so it polls with a SHORT bound and then says, in its status word (generation-tagged, write-
+    //      through), whether it TOOK its heads or GAVE UP - and leaves either way.  The primary merges its own heads, then
+    //      reads the status words (the helpers have their indices: resident, bounded) and merges whatever was given up.
+    //      (Round 3 let all nm mergers wait without bound: when every resident workgroup is such a merger the launch stalls
+    //      for the spin bound and merges stale partials.  The first round-4 form - the primary alone - pulled all 64 KiB of a
+    //      (b, kv head)'s partials through ONE CU: 2.3 us from "flags seen" to "output written" against 0.4 us for four
+    //      mergers, profiles/r04_stamps.txt.)  The host sets nmerge = 1 when the grid does not fit the chip.
+    //      Wave 0 polls (lane = split / helper); the decision reaches the other waves through LDS and a barrier; four waves
+    //      per head: waves 0-3 heads k, k + 2 nm, ..., waves 4-7 heads k + nm, k + 3 nm, ... ----
+    const int nm = ns > 1 ? (p.nmerge < ns ? (p.nmerge > 0 ? p.nmerge : 1) : ns) : 1;
+    const int km = idx - (ns - nm);                          // merger number; nm - 1 = the primary
+    if (ns > 1 && km >= 0) {
+        const bool primary = idx == ns - 1;
+        const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
+        __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)tail_rec(p, bh), 0, kRecWords * 4, 0x00020000);
+        if (wave == 0) {
             const int fo = (lane < ns ? lane : 0) * 4;
-            fault = true;
-            for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
+            bool seen = false;
+            const int bound = primary ? (1 << 20) : (p.tail_test ? 0 : 48);      // helper: ~30-50 us of polls, then it gives up
+            for (int spin = 0; spin < bound; ++spin) {       // bounded: a workgroup that never publishes must not hang the GPU
                 const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
-                if (__all(f == want)) { fault = false; break; }
+                if (__all(f == want)) { seen = true; break; }
                 __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) {
+                tl[4] = seen ? 1 : 0;
+                if (!primary) __builtin_amdgcn_raw_buffer_store_b32((want << 1) | (seen ? 0u : 1u), rr, (8 + km) * 4, 0, 16 /* sc1 */);
             }
             MILLION_STAMP(p, 11);
         }
+        __syncthreads();
+        const bool seen = tl[4] != 0;
+        const bool fault = primary && !seen;
         if (fault && tid == 0) atomicAdd(&g_tail_faults, 1u);      // the heads of this (b, kv head) come out as NaN
-        const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
-        for (int g = wave >> 2; g < G; g += 4)
-            tail_merge_heads<2>(p, b, hk, g, wave & 3, ns, src, lane, g + 2 < G, fault);
+        if (seen || primary)
+            for (int g = km + (wave >> 2) * nm; g < G; g += 4 * nm)
+                tail_merge_heads<2>(p, b, hk, g, 2 * nm, wave & 3, ns, src, lane, g + 2 * nm < G, fault);
+        if (primary && nm > 1) {
+            // what did the helpers do?  (their status words carry this launch's generation: nothing to reset)
+            if (wave == 0) {
+                const int ho = (8 + (lane < nm - 1 ? lane : 0)) * 4;
+                unsigned st = 0;
+                for (int spin = 0; spin < (1 << 20); ++spin) {
+                    st = __builtin_amdgcn_raw_buffer_load_b32(rr, ho, 0, 16);
+                    if (__all((st >> 1) == want)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned long long gave = __builtin_amdgcn_ballot_w64((st >> 1) != want || (st & 1u));   // (a helper that never answered counts as "gave up")
+                if (lane == 0) tl[5] = (int)(unsigned)(gave & ((1ull << (nm - 1)) - 1ull));
+            }
+            __syncthreads();
+            const unsigned gave = (unsigned)tl[5];
+            for (int h = 0; h < nm - 1; ++h)
+                if (gave >> h & 1u)
+                    for (int g = h + (wave >> 2) * nm; g < G; g += 4 * nm)
+                        tail_merge_heads<2>(p, b, hk, g, 2 * nm, wave & 3, ns, src, lane, g + 2 * nm < G, fault);
+        }
     }
     if (idx == ns - 1 && tid == 0) {
         // the workgroup that arrived last: its wave 0 has seen every flag of this launch (or ns == 1), so every workgroup of
@@ -1804,8 +1841,9 @@ int read_tail_faults() {
 }
 
 // A/B knob (million_set_force_generic 2): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only
-static int g_mfma_policy = 0;
-void set_mfma_policy(int policy) { g_mfma_policy = policy; }
+// g_tail_test (million_set_force_generic 4): the merge helpers give up at once - the last arriver's take-over path, for tests
+static int g_mfma_policy = 0, g_tail_test = 0;
+void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 1; }
 
 // split policy: about one workgroup per CU; a split is at least 512 tokens long
 static int mfma_splits(const AttnParams &p) {
@@ -1856,6 +1894,17 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     p.nsplit = ns;
     p.nslots = ns;
     p.split_len = len;
+    // mergers per (b, kv head): helpers only when every workgroup of the launch is resident at once (one per CU); a helper
+    // that still cannot see its flags gives up and the last arriver takes over (merge_and_publish)
+    {
+        int nm = p.G < ns ? p.G : ns;
+        if (nm > 8) nm = 8;
+        p.nmerge = (long long)bh * ns <= device_cus() ? (nm > 0 ? nm : 1) : 1;
+        p.tail_test = g_tail_test;
+#if MILLION_EXP & 2
+        p.nmerge = 1;      // A/B: the primary alone
+#endif
+    }
     if (device_once(1)) {
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);

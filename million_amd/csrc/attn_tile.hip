@@ -453,8 +453,10 @@ int launch_attn_tile(const AttnParams &p_in, hipStream_t s) {
     const int bh = p.bs * p.nh_k;
     const int cus = device_cus();
     const int waves = (p.d == 64 || p.dm == 8) ? 16 : 8;
-    // split policy: one workgroup per CU; a split is a multiple of 64 tokens and at least 256 tokens long
-    int ns = (cus + bh - 1) / bh;
+    // split policy: one workgroup per CU - the residual-window workgroup of every (b, kv head) included (rounds 2-3 sized the
+    // splits for all CUs and launched bh more workgroups than the chip holds at d = 128: the last ones started when the first
+    // finished); a split is a multiple of 64 tokens and at least 256 tokens long
+    int ns = cus > 2 * bh ? (cus - bh) / bh : (cus + bh - 1) / bh;
     if (ns > kMaxSplits) ns = kMaxSplits;
     int by_len = (p.T + 255) / 256;
     if (by_len < 1) by_len = 1;

@@ -57,6 +57,8 @@ struct AttnParams {
     int v_identity;  // V pages are a dense scratch pool: page id = bh * n_pages_cap + page (no id table)
     int nsplit;      // code splits per (b, hk)
     int nslots;      // partial slots per (b, hk)
+    int tail_test;   // diagnostics (million_set_force_generic(4)): the helpers of the merge give up at once
+    int nmerge;      // MFMA kernels: workgroups per (b, kv head) that merge heads (the last arriver + nmerge - 1 helpers); 1 when the grid does not fit the chip
     int split_len;   // tokens per split
     int slot_floats; // floats per partial slot = G*d + 2*G, padded to whole 128-byte lines (no line is shared by two slots)
     float scale_log2e;

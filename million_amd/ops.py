@@ -549,8 +549,8 @@ def lengths_advance(dev_lengths: torch.Tensor, n_flushed: int, resid_cap: int) -
 
 
 def set_force_generic(on) -> None:
-    """0 / False = auto, 1 / True = scalar fallback kernel only, 2 = grouped MFMA kernel instead of the streaming one
-    (million_hip.h: million_set_force_generic)."""
+    """0 / False = auto, 1 / True = scalar fallback kernel only, 2 = grouped MFMA kernel instead of the streaming one, 4 = auto
+    with the merge helpers giving up at once (million_hip.h: million_set_force_generic)."""
     L.load().million_set_force_generic(int(on))
 
 

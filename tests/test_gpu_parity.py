@@ -1336,6 +1336,32 @@ def test_attn_more_workgroups_than_resident_slots(bs, cap, T, r, env, oracle):
     assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1
 
 
+@pytest.mark.parametrize("bs,nh,nhk,T,r", [(1, 32, 8, 32768, 100), (2, 32, 8, 9000, 5), (1, 128, 8, 20000, 64), (1, 8, 8, 4096, 17)],
+                         ids=["headline", "two-requests", "sixteen-heads", "one-head"])
+def test_attn_merge_helpers_give_up(bs, nh, nhk, T, r, env, oracle):
+    """The split merge of the MFMA kernels: the last-arriving workgroup of a (b, kv head) is responsible for every head; the
+    workgroups that arrived just before it help (one head each) when they see every split's flag within a short bound, and
+    say so in a status word.  million_set_force_generic(4) makes every helper give up at once: the last arriver must then
+    merge all heads itself - same output, no fault; and with the helpers on, the same."""
+    torch, ops = env
+    from million_amd import _lib
+    c = synth.attn_case(9700 + nh + T % 31, bs, nh, nhk, 128, 64, 256, T, r)
+    gold = oracle.decode_attn(**c)
+    lib = _lib.load()
+    lib.million_debug_tail_faults()
+    try:
+        ops.set_force_generic(4)
+        for _ in range(2):      # status words of launch n must not confuse launch n + 1
+            out = _run_paged(torch, ops, oracle, c, 64, 256, 64)
+        _check(out, gold, "helpers give up")
+    finally:
+        ops.set_force_generic(0)
+    for _ in range(2):
+        out = _run_paged(torch, ops, oracle, c, 64, 256, 64)
+    _check(out, gold, "helpers take their heads")
+    assert lib.million_debug_tail_faults() == 0
+
+
 @pytest.mark.parametrize("M,T,r,bs", [(64, 5000, 17, 1), (32, 40000, 128, 1), (64, 33000, 64, 2), (64, 0, 40, 1), (32, 100, 1, 1)])
 def test_attn_c128_on_mfma(M, T, r, bs, env, oracle):
     """C = 128 centroids per subspace (nbits 7; the reference compiles C in {128, 256}, setup.py:15) on the streaming MFMA

@@ -22,7 +22,7 @@ vc = ops.prepare_cents(torch.randn(M, C, d // M, device=dev).half(), cache=False
 q = torch.randn(bs, nh, 1, d, device=dev).half()
 kr = torch.randn(bs, nhk, 128, d, device=dev).half()
 vr = torch.randn(bs, nhk, 128, d, device=dev).half()
-buf = torch.zeros(66 * bs * nhk * 4 * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(66 * bs * nhk * 16 * 8, dtype=torch.int64, device=dev)      # (splits + 1) x (b, kv head) x up to 16 waves x 8 words
 for it in range(3):
     buf.zero_()
     lib.million_debug_set_stamp_buffer(buf.data_ptr())
@@ -32,7 +32,7 @@ for it in range(3):
 a = buf.cpu().numpy().reshape(-1, 8)
 a = a[a[:, 4] > 0]
 tiles = a[:, 4].astype(float)
-names = ["fill_k (table reads + K^ writes)", "scores + softmax", "fill_v (table reads + perms + V^T writes)", "values"]
+names = ["K gathers -> score MFMAs, V gathers issued", "softmax", "packs + value MFMAs", "(unused)"]      # round 4: direct operand gathers
 print(f"waves with tiles: {len(a)}; tiles per wave: mean {tiles.mean():.1f}; wave lifetime mean {a[:, 5].mean():.0f} clocks")
 import numpy as np
 for i, n in enumerate(names):      # (the merge's own diagnostic stamps land in a few of these words: median, not mean)
