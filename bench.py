@@ -592,24 +592,30 @@ def cpu_baseline_encode(bs, nhk, d, M, C, cores):
     """the encode leg on the host's cores - the reference's CPU-runnable sa_encode_4d (torch.cdist + argmin,
     pq_utils.py:410-449; oracle.pq_encode_cdist_torch) and the direct form of its GPU encoder (pq_utils.py:483-494;
     oracle.pq_encode_direct_torch), fp32, on (i) one layer's flush page (page_size 64 rows x nh_k heads x requests, K and V
-    sides) and (ii) a 4096-token prompt slice of one request (K and V sides).  Bounded: <= ~4 s per cell."""
+    sides) and (ii) a 1024-token prompt slice of one request (K and V sides).  Bounded (~10-20 s in all): at most 32 torch
+    threads - on the 256-core GPU box these small dense ops ran 20-200 x SLOWER with one thread per core (85 s for one 4096-token
+    slice) than on 8 cores - and `cores` says how many were used."""
     import torch
     from oracle import oracle as O
+    used = max(1, min(cores, 32))
+    torch.set_num_threads(used)
     g = torch.Generator().manual_seed(11)
     cents = torch.randn(M, C, d // M, generator=g).half().float().numpy()
-    out = {"unit": "ms per layer, K and V sides", "cores": cores, "dtype": "f32"}
-    for name, n, nb in (("flush_page_64_rows", 64, bs), ("prompt_4096_tokens", 4096, 1)):
+    n_prompt = 1024
+    out = {"unit": "ms per layer, K and V sides", "cores": used, "dtype": "f32"}
+    for name, n, nb in (("flush_page_64_rows", 64, bs), (f"prompt_{n_prompt}_tokens", n_prompt, 1)):
         X = torch.randn(nb, nhk, n, d, generator=g).half().float().numpy()
         cell = {}
         for form, fn in (("cdist", O.pq_encode_cdist_torch), ("direct", O.pq_encode_direct_torch)):
             fn(X[:, :, :min(n, 64)], cents)      # warm-up
             t0, reps = time.perf_counter(), 0
-            while reps < 1 or (time.perf_counter() - t0 < 2.0 and reps < 20):
+            while reps < 1 or (time.perf_counter() - t0 < 1.5 and reps < 10):
                 fn(X, cents)
                 reps += 1
             cell[form] = round(2.0 * (time.perf_counter() - t0) / reps * 1e3, 3)      # x 2: K side and V side
         out[name] = cell
-    out["rows_per_s_direct_prompt"] = round(2 * nhk * 4096 / (out["prompt_4096_tokens"]["direct"] * 1e-3), 1)
+    out["rows_per_s_direct_prompt"] = round(2 * nhk * n_prompt / (out[f"prompt_{n_prompt}_tokens"]["direct"] * 1e-3), 1)
+    torch.set_num_threads(cores)
     return out
 
 
