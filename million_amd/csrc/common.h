@@ -202,9 +202,8 @@ typedef float mv4f __attribute__((ext_vector_type(4)));
 // AUX = cache-policy bits of the loads of handed-off bytes: 16 (sc1, agent scope).  (Round 2 switched to sc0 loads when
 // the ticket said every producer had run on the merger's XCD; an sc0 load may be served by the CU's L1, which nothing
 // refreshes - tools/micro/l2_handoff.hip shows polls with sc0 loads never seeing a later store - so that path is gone.)
-template <int G_, int AUX>
+template <int G_, int AUX, int kThreads = 512, int kD = 128>
 __device__ __forceinline__ void merge_vec4(const AttnParams &p, int b, int hk, const float *src, int ns, float *scratch) {
-    constexpr int kThreads = 512, kD = 128;
     constexpr int nq = G_ * kD / 4;            // float4 groups of the output
     constexpr int nsg = kThreads / nq;         // slot subsets = threads per group
     constexpr int kPer = (32 + nsg - 1) / nsg; // loads per thread (ns <= 32)
@@ -297,12 +296,16 @@ __device__ __forceinline__ void ticket_and_merge(const AttnParams &p, int b, int
     constexpr int kMergeBatch = 32;
     const int ns = p.nslots;
     const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
-    if (nthr == 512 && d == 128 && ns <= 32 && (G == 1 || G == 2 || G == 4 || G == 8)) {      // workgroup-uniform
+    if ((nthr == 512 || nthr == 1024) && (d == 128 || d == 64) && ns <= 32 && (G == 1 || G == 2 || G == 4 || G == 8)) {      // workgroup-uniform
         MILLION_STAMP(p, 11);
-        if (G == 4) merge_vec4<4, 16>(p, b, hk, src, ns, scratch);
-        else if (G == 8) merge_vec4<8, 16>(p, b, hk, src, ns, scratch);
-        else if (G == 2) merge_vec4<2, 16>(p, b, hk, src, ns, scratch);
-        else merge_vec4<1, 16>(p, b, hk, src, ns, scratch);
+#define MILLION_MV4(G_) \
+        { if (nthr == 512) { if (d == 128) merge_vec4<G_, 16, 512, 128>(p, b, hk, src, ns, scratch); else merge_vec4<G_, 16, 512, 64>(p, b, hk, src, ns, scratch); } \
+          else { if (d == 128) merge_vec4<G_, 16, 1024, 128>(p, b, hk, src, ns, scratch); else merge_vec4<G_, 16, 1024, 64>(p, b, hk, src, ns, scratch); } }
+        if (G == 4) MILLION_MV4(4)
+        else if (G == 8) MILLION_MV4(8)
+        else if (G == 2) MILLION_MV4(2)
+        else MILLION_MV4(1)
+#undef MILLION_MV4
         goto merged;
     }
     {

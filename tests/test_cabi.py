@@ -66,6 +66,37 @@ def test_argument_validation_without_gpu(lib):
     assert lib.million_prepared_cents_bytes(64, 256, 2) == 64 * 256 * 2 * (2 * 2 + 4)   # two fp16 images + one fp32
 
 
+def test_kernel_kind_policy_without_gpu(lib):
+    """million_attn_kernel_kind is host logic (no launch): which kernel a descriptor gets.  Every batch x context of the
+    streaming kernel's shapes stays on it (kind 1) - calls with more than 64 rounds per wave get more splits instead of the
+    grouped (5) or scalar (0) kernel (Interface.template.cu:45,62-77: the reference has one kernel for any (bs, nh, T)) - and the
+    tile kernel (3) takes the rest of the build matrix with up to 16 query heads per kv head in one launch."""
+    from million_amd import _lib
+
+    def kind(bs, nh, nh_k, T, d=128, M=64, C=256, paged=True):
+        q = _lib.AttnDesc()
+        q.struct_size = ctypes.sizeof(_lib.AttnDesc)
+        q.bs, q.nh, q.nh_k, q.d, q.M, q.C = bs, nh, nh_k, d, M, C
+        q.n_tokens, q.r, q.resid_cap, q.resid_start = T, 17, 128, 0
+        q.resid_stride_b, q.resid_stride_h = nh_k * 128 * d, 128 * d
+        q.k_layout = q.v_layout = _lib.MILLION_KV_PAGED if paged else _lib.MILLION_KV_ROWMAJOR
+        q.page_size, q.n_pages_cap = 64, max(1, (T + 63) // 64)
+        q.k_stride_b, q.k_stride_h, q.v_stride_b, q.v_stride_h = nh_k * T * M, T * M, nh_k * T * M, T * M
+        return lib.million_attn_kernel_kind(ctypes.byref(q))
+
+    assert kind(1, 32, 8, 32768) == 1
+    for bs, nh, nh_k, T, C in ((16, 32, 8, 40000, 256), (8, 32, 32, 32768, 256), (32, 32, 8, 20000, 128), (64, 32, 8, 131072, 256),
+                               (1, 32, 8, 1000000, 256)):
+        assert kind(bs, nh, nh_k, T, C=C) == 1, (bs, nh, nh_k, T, C)
+    assert kind(1, 32, 8, 0) == 5                      # nothing quantised yet: grouped MFMA kernel (window only)
+    assert kind(1, 32, 8, 4096, paged=False) == 2      # the reference's 10-argument layout: V transposed first
+    for d, M in ((128, 16), (64, 64), (64, 32), (64, 16)):
+        assert kind(1, 32, 8, 4096, d=d, M=M) == 3
+        assert kind(1, 128, 8, 4096, d=d, M=M) == 3    # 16 heads per kv head: still one tile-kernel launch
+        assert kind(1, 32, 8, 4096, d=d, M=M, paged=False) == 4
+    assert kind(1, 32, 8, 4096, C=64) == 0             # off the build matrix: scalar kernel
+
+
 def test_bindings_exports_reference_names():
     import bindings
     # the 240 names the reference generates (setup.py:26-54) ...

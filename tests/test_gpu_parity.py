@@ -2064,3 +2064,38 @@ def test_paged_cache_request_lifecycle_recycled_slot(env, oracle):
     np.testing.assert_array_equal(kf2.cpu().numpy(), want)
     want_v = np.concatenate([oracle.pq_decode(oracle.pq_encode(V[:, :, :90], cv), cv).astype(np.float16), V[:, :, 90:100]], axis=2)
     np.testing.assert_array_equal(vf2.cpu().numpy(), want_v)
+
+
+def test_attn_two_streams_share_the_chip(env, oracle):
+    """Two streams launch decode attention at the same time (separate workspaces): the workgroups of the two grids share the
+    CUs, so a workgroup of one launch may wait long for its later arrivals to be dispatched - the case in which round 3's
+    unbounded mergers could stall and merge stale partials.  The merge protocol (last arriver owns the merge, helpers with a
+    bounded wait) must give the same outputs as the calls one after the other, with no fault."""
+    torch, ops = env
+    from million_amd import _lib
+    nh, nhk, M, C, ps = 32, 8, 64, 256, 64
+    cases = [synth.attn_case(9800 + i, 2, nh, nhk, 128, M, C, 9000 + 64 * i, 50 + i) for i in range(2)]
+    golds = [oracle.decode_attn(**c) for c in cases]
+    lib = _lib.load()
+    lib.million_debug_tail_faults()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    prepared = []
+    for c in cases:
+        t = _dev(torch, c)
+        vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+        kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+        prepared.append(dict(t=t, kpool=torch.from_numpy(kpool).cuda(), vpool=torch.from_numpy(vpool).cuda(),
+                             ids=torch.from_numpy(ids.astype(np.int32)).cuda(),
+                             kp=ops.prepare_cents(t["k_cents"], cache=False), vp=ops.prepare_cents(t["v_cents"], cache=False)))
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(20):                       # many overlapping pairs of launches
+        for i, (st, pr, c) in enumerate(zip(streams, prepared, cases)):
+            with torch.cuda.stream(st):
+                outs[i] = ops.pq_decode_attn(pr["t"]["q"], pr["kpool"], pr["vpool"], pr["kp"], pr["vp"], pr["t"]["k_res"],
+                                             pr["t"]["v_res"], c["r"], M=M, C=C, n_tokens=c["k_codes"].shape[2],
+                                             k_page_ids=pr["ids"], v_page_ids=pr["ids"], page_size=ps)
+    torch.cuda.synchronize()
+    assert lib.million_debug_tail_faults() == 0
+    for o, g in zip(outs, golds):
+        _check(o.cpu().numpy(), g, "two streams")
