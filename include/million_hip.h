@@ -236,7 +236,9 @@ int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Kernel choice for A/B measurements and tests: 0 = auto (default), 1 = generic kernel only, 2 = MFMA grouped kernel
  * only (never the streaming one), 4 = auto, but the helper workgroups of the split merge give up at once (exercises the
- * last arriver's take-over path of the MFMA kernels' tail). */
+ * last arriver's take-over path of the MFMA kernels' tail: every give-up bit is set before the launch's first ticket),
+ * 8 = auto, but the helpers have no patience: each gives up through the real path (its atomic on the ticket word) unless
+ * every workgroup has already taken its ticket. */
 void million_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------

@@ -655,7 +655,11 @@ __device__ __forceinline__ unsigned tail_xcc() { return __builtin_amdgcn_s_getre
 // lane: the body still ran 1.4 us longer.)
 __device__ __forceinline__ void tail_mark_xcd(const AttnParams &p, int bh, int split, int wave, int lane) {
     if (wave == 0) {
-        if (lane == 0) __hip_atomic_store(tail_flags(p, bh) + kFlagWords + split, tail_xcc() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(tail_flags(p, bh) + kFlagWords + split, tail_xcc() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // diagnostics (million_set_force_generic(4)): every helper "has given up" before anybody's ticket
+            if (p.tail_test == 1) __hip_atomic_fetch_or(tail_rec(p, bh) + 2, 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -666,8 +670,8 @@ __device__ __forceinline__ void tail_mark_xcd(const AttnParams &p, int bh, int s
 // no conditional vector-memory operation for hipcc's wait counting - but only the lanes named above address inside the
 // descriptors; the hardware drops out-of-range lanes (loads return 0).
 struct TailReq {
-    int idx;
-    unsigned gen, cen;
+    int idx;        // RAW ticket word as the atomic returned it: give-up bits [7:0], arrival count [31:8] (see merge_and_publish)
+    unsigned gen, cen, base;
     bool done;      // wave-uniform: false = this wave never passed the early request point (it had no whole round)
 };
 __device__ __forceinline__ void tail_request(const AttnParams &p, int bh, int ns, int wave, int lane, TailReq &t) {
@@ -676,8 +680,9 @@ __device__ __forceinline__ void tail_request(const AttnParams &p, int bh, int ns
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(tail_flags(p, bh) + kFlagWords), 0, kFlagWords * 4, 0x00020000);
     const bool one = wave == kNW - 1 && lane == 0;
     t.cen = __builtin_amdgcn_raw_buffer_load_b32(rc, wave == 0 ? (lane < ns ? lane : 0) * 4 : kOut, 0, 16);
-    t.idx = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rr, one ? 2 * 4 : kOut, 0, 0);
+    t.idx = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(256, rr, one ? 2 * 4 : kOut, 0, 0);
     t.gen = __builtin_amdgcn_raw_buffer_load_b32(rr, one ? 3 * 4 : kOut, 0, 16);
+    t.base = __builtin_amdgcn_raw_buffer_load_b32(rr, one ? 4 * 4 : kOut, 0, 16);
     t.done = true;
 }
 
@@ -778,7 +783,8 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     // ---- census line / arrival index / generation: requested ~3 us ago by the streaming loop (tail_request); a wave that
     //      had no whole round asks now ----
     if (!treq.done) tail_request(p, bh, ns, wave, lane, treq);
-    const int idx_v = treq.idx;
+    const unsigned raw_v = (unsigned)treq.idx;
+    const int idx_v = (int)(((raw_v >> 8) - treq.base) & 0xffffffu);      // arrival index of this workgroup within this launch
     const unsigned gen_v = treq.gen, cen_v = treq.cen;
     // ---- merge the waves of this workgroup through LDS (tables are dead after the barrier) ----
     l_run = rows_sum(l_run);
@@ -877,7 +883,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         }
     }
     STAMP(5);
-    if (wave == kNW - 1 && lane == 0) { tl[1] = idx_v; tl[2] = (int)gen_v; }      // the index and the generation have arrived
+    if (wave == kNW - 1 && lane == 0) { tl[1] = idx_v; tl[2] = (int)gen_v; tl[5] = (int)(raw_v & 0xffu); tl[6] = (int)treq.base; }      // the index, the generation, the give-up bits and the base have arrived
     // a storing wave's partial is out of the CU (in L2, or in memory) when its vmcnt retires; the flag is raised behind the
     // barrier every storing wave then joins (cdna_hip_programming.md Guideline 16, R1)
     if (ns > 1 && wave < nsw) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -895,72 +901,90 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     // ---- the merge (round 4).  The workgroup whose arrival index is ns - 1 - the PRIMARY - is responsible for every head:
     //      every workgroup it waits for has taken its index, i.e. is resident, on its way to its own flag store, and waits
     //      for nothing itself, so its polls end under ANY dispatch order and residency.  The nm - 1 workgroups that arrived
-    //      just before it are HELPERS (merger k = idx - (ns - nm) takes heads k, k + nm, ...): a helper needs flags of
+    //      just before it are HELPERS (merger k = idx - (ns - nm) takes heads k, k + nm, ...).  A helper needs the flags of
     //      workgroups that arrived AFTER it and may not even be dispatched (more workgroups than resident slots; two launches
-    //      sharing the chip), so it polls with a SHORT bound and then says, in its status word (generation-tagged, write-
-    //      through), whether it TOOK its heads or GAVE UP - and leaves either way.  The primary merges its own heads, then
-    //      reads the status words (the helpers have their indices: resident, bounded) and merges whatever was given up.
-    //      (Round 3 let all nm mergers wait without bound: when every resident workgroup is such a merger the launch stalls
-    //      for the spin bound and merges stale partials.  The first round-4 form - the primary alone - pulled all 64 KiB of a
-    //      (b, kv head)'s partials through ONE CU: 2.3 us from "flags seen" to "output written" against 0.4 us for four
-    //      mergers, profiles/r04_stamps.txt.)  The host sets nmerge = 1 when the grid does not fit the chip.
-    //      Wave 0 polls (lane = split / helper); the decision reaches the other waves through LDS and a barrier; four waves
-    //      per head: waves 0-3 heads k, k + 2 nm, ..., waves 4-7 heads k + nm, k + 3 nm, ... ----
+    //      sharing the chip), so it first looks - with a SHORT bound - whether every workgroup has taken its index: then all
+    //      are resident and the flags will come.  If the bound runs out it GIVES UP, and the primary must know.  Both facts live
+    //      in ONE word, the ticket word of the (b, kv head): arrival count in bits 31:8 (a ticket is an atomic add of 256),
+    //      give-up bits 7:0 (an atomic add of 1 << k by helper k alone).  Atomics on one word are serialised, so a helper's give-up either precedes the
+    //      last ticket - then the primary's own ticket, fetched ~3 us before its tail, RETURNED the bit - or follows it - then
+    //      the give-up atomic returns a full count and the helper takes its heads after all.  Nobody polls anybody's status.
+    //      The count is never reset (a straggling helper of this launch must never read a count that looks incomplete): a
+    //      launch's indices are counted from `base`, which the primary moves on by ns at the end, together with the generation.
+    //      (Round 3 let all nm mergers wait for flags without bound: when every resident workgroup is such a merger the launch
+    //      stalls for the spin bound and merges stale partials.  The primary alone pulls all 64 KiB of a (b, kv head)'s
+    //      partials through ONE CU: +1.2 us per launch at one request; helpers that report through status words the primary
+    //      polls: +0.8 us, profiles/r04_ab_merge.txt.)  The host sets nmerge = 1 when the grid does not fit the chip.
+    //      Every merging wave polls the flags itself (lane = split) and merges behind its own match; four waves per head:
+    //      waves 0-3 heads k, k + 2 nm, ..., waves 4-7 heads k + nm, k + 3 nm, ... ----
     const int nm = ns > 1 ? (p.nmerge < ns ? (p.nmerge > 0 ? p.nmerge : 1) : ns) : 1;
     const int km = idx - (ns - nm);                          // merger number; nm - 1 = the primary
     if (ns > 1 && km >= 0) {
         const bool primary = idx == ns - 1;
         const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
         __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)tail_rec(p, bh), 0, kRecWords * 4, 0x00020000);
-        if (wave == 0) {
-            const int fo = (lane < ns ? lane : 0) * 4;
-            bool seen = false;
-            const int bound = primary ? (1 << 20) : (p.tail_test ? 0 : 48);      // helper: ~30-50 us of polls, then it gives up
-            for (int spin = 0; spin < bound; ++spin) {       // bounded: a workgroup that never publishes must not hang the GPU
-                const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
-                if (__all(f == want)) { seen = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (lane == 0) {
-                tl[4] = seen ? 1 : 0;
-                if (!primary) __builtin_amdgcn_raw_buffer_store_b32((want << 1) | (seen ? 0u : 1u), rr, (8 + km) * 4, 0, 16 /* sc1 */);
-            }
-            MILLION_STAMP(p, 11);
-        }
-        __syncthreads();
-        const bool seen = tl[4] != 0;
-        const bool fault = primary && !seen;
-        if (fault && tid == 0) atomicAdd(&g_tail_faults, 1u);      // the heads of this (b, kv head) come out as NaN
-        if (seen || primary)
-            for (int g = km + (wave >> 2) * nm; g < G; g += 4 * nm)
-                tail_merge_heads<2>(p, b, hk, g, 2 * nm, wave & 3, ns, src, lane, g + 2 * nm < G, fault);
-        if (primary && nm > 1) {
-            // what did the helpers do?  (their status words carry this launch's generation: nothing to reset)
+        const int fo = (lane < ns ? lane : 0) * 4;
+        bool take = true;
+        if (!primary) {
             if (wave == 0) {
-                const int ho = (8 + (lane < nm - 1 ? lane : 0)) * 4;
-                unsigned st = 0;
-                for (int spin = 0; spin < (1 << 20); ++spin) {
-                    st = __builtin_amdgcn_raw_buffer_load_b32(rr, ho, 0, 16);
-                    if (__all((st >> 1) == want)) break;
+                __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)tail_rec(p, bh), 0, kRecWords * 4, 0x00020000);
+                const unsigned base = (unsigned)tl[6];
+                bool all_in = false;
+                const int polls = p.tail_test ? 0 : 48;                       // ~30-50 us; test modes: no patience at all
+                for (int spin = 0; spin < polls; ++spin) {
+                    const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rr, 2 * 4, 0, 16);
+                    if ((((w >> 8) - base) & 0xffffffu) >= (unsigned)ns) { all_in = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                const unsigned long long gave = __builtin_amdgcn_ballot_w64((st >> 1) != want || (st & 1u));   // (a helper that never answered counts as "gave up")
-                if (lane == 0) tl[5] = (int)(unsigned)(gave & ((1ull << (nm - 1)) - 1ull));
+                if (!all_in && p.tail_test != 1) {      // give up - unless the give-up atomic itself finds everybody in
+                                                        // (test mode 1: the bits were all set in the prologue)
+                    // ONE lane adds (the other lanes' offsets are out of range: dropped, they return 0); helper k is the only one
+                    // that ever touches bit k between two clears, so the add never carries
+                    constexpr int kOut = 1 << 20;
+                    const unsigned old = (unsigned)__builtin_amdgcn_readfirstlane(
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1 << km, rr, lane == 0 ? 2 * 4 : kOut, 0, 0));
+                    all_in = (((old >> 8) - base) & 0xffffffu) >= (unsigned)ns;
+                }
+                if (lane == 0) tl[4] = all_in ? 1 : 0;
             }
             __syncthreads();
-            const unsigned gave = (unsigned)tl[5];
-            for (int h = 0; h < nm - 1; ++h)
-                if (gave >> h & 1u)
-                    for (int g = h + (wave >> 2) * nm; g < G; g += 4 * nm)
-                        tail_merge_heads<2>(p, b, hk, g, 2 * nm, wave & 3, ns, src, lane, g + 2 * nm < G, fault);
+            take = tl[4] != 0;
+        }
+        if (take) {
+            bool fault = true;
+            for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
+                const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                if (__all(f == want)) { fault = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            MILLION_STAMP(p, 11);
+            if (fault && lane == 0) atomicAdd(&g_tail_faults, 1u);      // this wave's outputs are written as NaN
+            // the heads this workgroup merges: its own (km, km + nm, ...) and - the primary - those of the helpers that gave up
+            // before it took its index (bits of its own ticket).  ONE call site: the merge runs once per workgroup from a cold
+            // instruction cache, and every inlined copy more made it slower (five copies: 1.6-2.3 us from "flags seen" to the
+            // end, round 3's single copy: 1.25).  Four waves per head: waves 0-3 take the even positions of the list, 4-7 the odd.
+            unsigned hm = 0;
+            for (int g = km; g < G; g += nm) hm |= 1u << g;
+            if (primary && nm > 1) {
+                const unsigned gave = (unsigned)tl[5] & ((1u << (nm - 1)) - 1u);
+                for (int h = 0; h < nm - 1; ++h)
+                    if (gave >> h & 1u)
+                        for (int g = h; g < G; g += nm) hm |= 1u << g;
+            }
+            int pos = 0;
+            for (int g = 0; g < G; ++g)
+                if (hm >> g & 1u) {
+                    if ((pos & 1) == (wave >> 2)) tail_merge_heads<1>(p, b, hk, g, 0, wave & 3, ns, src, lane, false, fault);
+                    ++pos;
+                }
         }
     }
     if (idx == ns - 1 && tid == 0) {
         // the workgroup that arrived last: its wave 0 has seen every flag of this launch (or ns == 1), so every workgroup of
         // this (b, kv head) has read the census line and the generation and stored its partial
         unsigned *rec = tail_rec(p, bh);
-        __hip_atomic_store(rec + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_and(rec + 2, ~0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // give-up bits off; the count stays
+        __hip_atomic_store(rec + 4, ((unsigned)tl[6] + (unsigned)ns) & 0xffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(rec + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // fused append with device-resident lengths: every workgroup of batch b has read its lengths once all nh_k
         // heads have got this far; the last of them advances r
@@ -1214,7 +1238,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_mfma_kernel(AttnParams p) {
 #undef UNIT_T
     STAMP(3);
     TailReq treq;
-    treq.done = false;
+    treq.idx = 0; treq.gen = 0; treq.cen = 0; treq.base = 0; treq.done = false;
     merge_and_publish<MS>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, m_run, l_run, treq);
 #undef STAMP
 }
@@ -1732,7 +1756,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     const int n_whole = n_mine >> 2, n_rem = n_mine & 3;      // whole rounds of four units + up to three more
     TailReq treq;
-    treq.idx = 0; treq.gen = 0; treq.cen = 0; treq.done = false;
+    treq.idx = 0; treq.gen = 0; treq.cen = 0; treq.base = 0; treq.done = false;
     {
         // prologue: the 8 score stages of round 0 (masked out when the wave has no whole round: its units are all
         // handled as single units below); round 2 is requested in between
@@ -1841,9 +1865,10 @@ int read_tail_faults() {
 }
 
 // A/B knob (million_set_force_generic 2): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only
-// g_tail_test (million_set_force_generic 4): the merge helpers give up at once - the last arriver's take-over path, for tests
+// g_tail_test (million_set_force_generic 4 / 8): the merge helpers give up at once - the last arriver's take-over path, for
+// tests: 1 = every give-up bit is set in the prologue, 2 = the helpers give up through the real path (no polls, then the atomic)
 static int g_mfma_policy = 0, g_tail_test = 0;
-void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 1; }
+void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 3; }
 
 // split policy: about one workgroup per CU; a split is at least 512 tokens long
 static int mfma_splits(const AttnParams &p) {

@@ -16,9 +16,10 @@ constexpr int kCntBytes = 1024;     // granule of the counter / flag blocks at t
 // Workspace head: one 128-byte record per (b, kv head), then one int per batch item (second-level ticket), then
 // 2 x kFlagWords words per (b, kv head) (split flags, XCD census line), then the split partials.  Record words (u32):
 //   [0..1]  u64 arrival ticket of the round-2 hand-off (ticket_and_merge below: tile and scalar kernels)
-//   [2]     arrival counter } L2 hand-off of the MFMA kernels (attn_mfma.hip, "Tail"): index of a workgroup among those
-//   [3]     generation      } of its (b, kv head) in the order they reach their tails; flags of launch n carry generation + 1
-// Every word is back at its resting value (0; generation advanced) when a launch ends.
+//   [2]     ticket word     } L2 hand-off of the MFMA kernels (attn_mfma.hip, "Tail"): arrival count of the (b, kv head)'s
+//   [3]     generation      } workgroups in bits 31:8 (never reset: a launch counts from [4]), give-up bits of the merge helpers
+//   [4]     count base      } in bits 7:0; flags of launch n carry generation + 1
+// Every word is at rest when a launch ends (ticket [0..1] zero, give-up bits zero, generation and base advanced).
 constexpr int kRecWords = 32;
 constexpr int kFlagWords = 64;      // one flag per split (the MFMA kernels use at most kMaxSplits = 64 slots)
 
@@ -57,7 +58,7 @@ struct AttnParams {
     int v_identity;  // V pages are a dense scratch pool: page id = bh * n_pages_cap + page (no id table)
     int nsplit;      // code splits per (b, hk)
     int nslots;      // partial slots per (b, hk)
-    int tail_test;   // diagnostics (million_set_force_generic(4)): the helpers of the merge give up at once
+    int tail_test;   // diagnostics (million_set_force_generic(4 / 8)): the helpers of the merge give up at once (1: preset bits, 2: real path)
     int nmerge;      // MFMA kernels: workgroups per (b, kv head) that merge heads (the last arriver + nmerge - 1 helpers); 1 when the grid does not fit the chip
     int split_len;   // tokens per split
     int slot_floats; // floats per partial slot = G*d + 2*G, padded to whole 128-byte lines (no line is shared by two slots)

@@ -52,8 +52,9 @@ def _run_rowmajor(torch, ops, c, M, C):
     return out.cpu().numpy()
 
 
-def _run_paged(torch, ops, oracle, c, M, C, ps, k_paged=True, shuffle=True, i64=False):
+def _run_paged(torch, ops, oracle, c, M, C, ps, k_paged=True, shuffle=True, i64=False, poison_out=False):
     t = _dev(torch, c)
+    dst = torch.full_like(t["q"], float("nan")) if poison_out else None      # a head nobody writes must show
     vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
     kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
     if shuffle and vpool.shape[0] > 1:      # physical page order must not matter
@@ -66,7 +67,7 @@ def _run_paged(torch, ops, oracle, c, M, C, ps, k_paged=True, shuffle=True, i64=
     vp = ops.prepare_cents(t["v_cents"], cache=False)
     out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda() if k_paged else t["k_codes"],
                              torch.from_numpy(vpool).cuda(), kp, vp, t["k_res"], t["v_res"], c["r"], M=M, C=C,
-                             n_tokens=T, k_page_ids=ids_t if k_paged else None, v_page_ids=ids_t, page_size=ps)
+                             n_tokens=T, k_page_ids=ids_t if k_paged else None, v_page_ids=ids_t, page_size=ps, out=dst)
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -1349,16 +1350,41 @@ def test_attn_merge_helpers_give_up(bs, nh, nhk, T, r, env, oracle):
     gold = oracle.decode_attn(**c)
     lib = _lib.load()
     lib.million_debug_tail_faults()
-    try:
-        ops.set_force_generic(4)
-        for _ in range(2):      # status words of launch n must not confuse launch n + 1
-            out = _run_paged(torch, ops, oracle, c, 64, 256, 64)
-        _check(out, gold, "helpers give up")
-    finally:
-        ops.set_force_generic(0)
+    for mode in (4, 8):      # 4: every give-up bit preset; 8: the helpers give up through their own atomic (no polls first)
+        try:
+            ops.set_force_generic(mode)
+            for _ in range(3):      # the ticket word of launch n must not confuse launch n + 1
+                out = _run_paged(torch, ops, oracle, c, 64, 256, 64)
+                _check(out, gold, f"helpers give up (mode {mode})")
+        finally:
+            ops.set_force_generic(0)
     for _ in range(2):
         out = _run_paged(torch, ops, oracle, c, 64, 256, 64)
     _check(out, gold, "helpers take their heads")
+    assert lib.million_debug_tail_faults() == 0
+
+
+def test_attn_merge_every_workgroup_is_a_merger(env, oracle):
+    """8 requests x 8 kv heads at 32K tokens: 4 splits per (b, kv head) and 4 query heads, so EVERY workgroup of the launch
+    is a merger and the first arriver of a pair is helper 0 - it waits for workgroups still streaming tens of microseconds of
+    codes, runs out of patience on real launches and gives up through its atomic; the primary must then find the bit in its
+    own ticket.  (Round 4 shipped a build for an hour whose give-up was added by all 64 lanes of the wave - bit k + 6, which
+    the primary masks off: heads never written.  No test had helpers that give up on their own.)  Repeated: the outcome depends
+    on arrival order."""
+    torch, ops = env
+    from million_amd import _lib
+    c = synth.attn_case(9911, 8, 32, 8, 128, 64, 256, 32768, 64)
+    gold = oracle.decode_attn(**c)
+    lib = _lib.load()
+    lib.million_debug_tail_faults()
+    for mode in (0, 8, 0):
+        try:
+            ops.set_force_generic(mode)
+            for it in range(4):
+                out = _run_paged(torch, ops, oracle, c, 64, 256, 64, poison_out=True)
+                _check(out, gold, f"every workgroup merges (mode {mode}, launch {it})")
+        finally:
+            ops.set_force_generic(0)
     assert lib.million_debug_tail_faults() == 0
 
 

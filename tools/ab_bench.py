@@ -84,6 +84,10 @@ for cfg in args.cfg:
     lib.million_set_force_generic(0)
     out = run(0).float()
     err = ((out - ref).norm() / ref.norm()).item()
+    if not (err < 1e-2):      # say where: (request, head) pairs that differ, and whether a merge gave up on a flag
+        bad = ((out - ref).abs().amax(-1) > 1e-2) | out.isnan().any(-1)
+        faults = lib.million_debug_tail_faults() if hasattr(lib, "million_debug_tail_faults") else -1
+        print(f"  MISMATCH: {int(bad.sum())} of {bad.numel()} (request, head) rows differ; tail faults {faults}; rows {bad.nonzero().flatten().tolist()[:64]}", flush=True)
     def timed(iters):
         # ONE captured graph of the launches, replayed; the timed replay follows a warm replay directly.  (Through round 3 the
         # region was enqueued eagerly behind a device-side sleep, to keep the host ahead: the chip drops its clocks during the

@@ -116,5 +116,13 @@ la = s[:, 0, :][s[:, 0, 11] != 0]
 if la.shape[0]:
     print("  mergers (%d): barrier -> every flag seen %.2f | -> head merged, out written %.2f us" % (
         la.shape[0], ((la[:, 11] - la[:, 10]) / 100.0).mean(), ((la[:, 6] - la[:, 11]) / 100.0).mean()))
+    idxs = la[:, 13] - 1
+    prim = la[idxs == idxs.max()]
+    help_ = la[idxs != idxs.max()]
+    for name, rows in (("primary (last arriver)", prim), ("helpers", help_)):
+        if rows.shape[0]:
+            print("    %-24s (%3d): barrier -> flags seen %.2f | -> end %.2f us (min %.2f max %.2f)" % (
+                name, rows.shape[0], ((rows[:, 11] - rows[:, 10]) / 100.0).mean(), ((rows[:, 6] - rows[:, 11]) / 100.0).mean(),
+                ((rows[:, 6] - rows[:, 11]) / 100.0).min(), ((rows[:, 6] - rows[:, 11]) / 100.0).max()))
 e = (s[:, 0, 6] - t0) / 100.0
 print("  end relative to first start: mean %.2f max %.2f us" % (e.mean(), e.max()))
