@@ -672,6 +672,7 @@ __device__ __forceinline__ void tail_mark_xcd(const AttnParams &p, int bh, int s
 struct TailReq {
     int idx;        // RAW ticket word as the atomic returned it: give-up bits [7:0], arrival count [31:8] (see merge_and_publish)
     unsigned gen, cen, base;
+    int nm, tt;     // mergers per (b, kv head) and the tail's test mode: kernel arguments, read here - not on the tail's critical path
     bool done;      // wave-uniform: false = this wave never passed the early request point (it had no whole round)
 };
 __device__ __forceinline__ void tail_request(const AttnParams &p, int bh, int ns, int wave, int lane, TailReq &t) {
@@ -683,6 +684,8 @@ __device__ __forceinline__ void tail_request(const AttnParams &p, int bh, int ns
     t.idx = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(256, rr, one ? 2 * 4 : kOut, 0, 0);
     t.gen = __builtin_amdgcn_raw_buffer_load_b32(rr, one ? 3 * 4 : kOut, 0, 16);
     t.base = __builtin_amdgcn_raw_buffer_load_b32(rr, one ? 4 * 4 : kOut, 0, 16);
+    t.nm = ns > 1 ? (p.nmerge < ns ? (p.nmerge > 0 ? p.nmerge : 1) : ns) : 1;
+    t.tt = p.tail_test;
     t.done = true;
 }
 
@@ -709,63 +712,54 @@ __device__ unsigned g_tail_faults = 0;
 
 // One query head is merged by FOUR waves: wave part (0..3) owns outputs [32 part, 32 part + 32) of the head; its lane
 // (h, q8) owns float4 q8 of those for the splits s = h (mod 8): ns / 8 16-byte loads per lane, the eight split subsets are
-// summed with DPP / row swaps.  NJ = 2 merges heads g and g + gstep in one pass: every load of both heads is issued before the
-// first reduction (one memory round trip for the pair; round 4: the ONE merging workgroup serves all heads, see
-// merge_and_publish).  `second` is wave-uniform: false = only head g.
-template <int NJ>
-__device__ __forceinline__ void tail_merge_heads(const AttnParams &p, int b, int hk, int g, int gstep, int part, int ns, const float *src,
-                                                 int lane, bool second, bool fault) {
+// summed with DPP / row swaps.  (A two-heads-per-pass variant - both heads' loads in flight before the first reduction - paid
+// when ONE workgroup merged every head; with the helpers back each merger has one head per wave group and the second
+// instantiation only made the cold tail longer.)
+__device__ __forceinline__ void tail_merge_head(const AttnParams &p, int b, int hk, int g, int part, int ns, const float *src, int lane,
+                                                bool fault) {
     const int q8 = lane & 7, h = lane >> 3;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
     // softmax weights of the splits (lane = split)
     const bool on = lane < ns;
     const int sl = on ? lane : 0;
-    float m1[NJ], l1[NJ];
-    v4u v[NJ][8];
+    const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + g) * 4, 0, 16));
+    const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + g) * 4, 0, 16));
+    v4u v[8];
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const int gj = (jj == 0 || second) ? g + gstep * jj : g;      // a missing second head re-reads the first (never a conditional load)
-        m1[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + gj) * 4, 0, 16));
-        l1[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + gj) * 4, 0, 16));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int slot = 8 * k + h;
-            const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
-            if (k < 4 || ns > 32)                                          // wave-uniform: the second half only for more than 32 splits
-                v[jj][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + gj * 128 + 32 * part + 4 * q8) * 4, 0, 16);
-            else
-                v[jj][k] = v4u{0, 0, 0, 0};
-        }
+    for (int k = 0; k < 8; ++k) {
+        const int slot = 8 * k + h;
+        const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
+        if (k < 4 || ns > 32)                                          // wave-uniform: the second half only for more than 32 splits
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * 128 + 32 * part + 4 * q8) * 4, 0, 16);
+        else
+            v[k] = v4u{0, 0, 0, 0};
     }
+    const float m0 = on ? m1 : -INFINITY;
+    const float l0 = on ? l1 : 0.f;
+    const float mx = wave_max_valu(m0);
+    const float ms_ = mx > -INFINITY ? mx : 0.f;
+    const float w0 = fast_exp2(m0 - ms_);                               // -inf -> 0 (lanes >= ns: 0)
+    // unnormalised sum first, 1 / (sum of w l) at the end: the denominator's reduction runs beside the accumulation
+    v4f32 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        if (jj == 1 && !second) break;
-        const float m0 = on ? m1[jj] : -INFINITY;
-        const float l0 = on ? l1[jj] : 0.f;
-        const float mx = wave_max_valu(m0);
-        const float ms_ = mx > -INFINITY ? mx : 0.f;
-        const float w0 = fast_exp2(m0 - ms_);                               // -inf -> 0 (lanes >= ns: 0)
-        // unnormalised sum first, 1 / (sum of w l) at the end: the denominator's reduction runs beside the accumulation
-        v4f32 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 8; ++k) {
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (8 * k + h), __builtin_bit_cast(int, w0)));
+        acc += w * __builtin_bit_cast(v4f32, v[k]);
+    }
+    const float den = wave_sum_valu(w0 * l0);
+    // nothing to attend to: 0; a merge that gave up on a flag: NaN, never a stale partial's sum
+    const float inv = fault ? __builtin_nanf("") : den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;
+    // sum over the eight split subsets: lanes l, l ^ 8 (same 16-lane row), then the four rows
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (8 * k + h), __builtin_bit_cast(int, w0)));
-            acc += w * __builtin_bit_cast(v4f32, v[jj][k]);
-        }
-        const float den = wave_sum_valu(w0 * l0);
-        const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;    // nothing to attend to: 0
-        // sum over the eight split subsets: lanes l, l ^ 8 (same 16-lane row), then the four rows
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x = acc[c];
-            x += MILLION_DPP(x, 0x128);      // row_ror:8
-            acc[c] = fault ? __builtin_nanf("") : rows_sum(x) * inv;
-        }
-        if (lane < 8) {
-            typedef f16 h4 __attribute__((ext_vector_type(4)));
-            const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-            *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g + gstep * jj) * 128 + 32 * part + 4 * q8) = o;
-        }
+    for (int c = 0; c < 4; ++c) {
+        float x = acc[c];
+        x += MILLION_DPP(x, 0x128);      // row_ror:8
+        acc[c] = rows_sum(x) * inv;
+    }
+    if (lane < 8) {
+        typedef f16 h4 __attribute__((ext_vector_type(4)));
+        const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * 128 + 32 * part + 4 * q8) = o;
     }
 }
 
@@ -917,66 +911,73 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     //      polls: +0.8 us, profiles/r04_ab_merge.txt.)  The host sets nmerge = 1 when the grid does not fit the chip.
     //      Every merging wave polls the flags itself (lane = split) and merges behind its own match; four waves per head:
     //      waves 0-3 heads k, k + 2 nm, ..., waves 4-7 heads k + nm, k + 3 nm, ... ----
-    const int nm = ns > 1 ? (p.nmerge < ns ? (p.nmerge > 0 ? p.nmerge : 1) : ns) : 1;
+    const int nm = treq.nm;
     const int km = idx - (ns - nm);                          // merger number; nm - 1 = the primary
     if (ns > 1 && km >= 0) {
         const bool primary = idx == ns - 1;
         const float *src = p.ws_part + (long long)bh * ns * p.slot_floats;
         __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)tail_flags(p, bh), 0, kFlagWords * 4, 0x00020000);
         const int fo = (lane < ns ? lane : 0) * 4;
-        bool take = true;
-        if (!primary) {
-            if (wave == 0) {
-                __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)tail_rec(p, bh), 0, kRecWords * 4, 0x00020000);
-                const unsigned base = (unsigned)tl[6];
-                bool all_in = false;
-                const int polls = p.tail_test ? 0 : 48;                       // ~30-50 us; test modes: no patience at all
-                for (int spin = 0; spin < polls; ++spin) {
-                    const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rr, 2 * 4, 0, 16);
-                    if ((((w >> 8) - base) & 0xffffffu) >= (unsigned)ns) { all_in = true; break; }
+        const int tt = treq.tt;
+        // The common path is short and straight (this code runs once per workgroup from a cold instruction cache: round 4
+        // measured +0.3 us from the barrier to "flags seen" and +0.35 us over the merge for a tail with loops over head masks
+        // and kernel arguments read here): poll, merge; what happens when a helper's patience runs out, and the primary's
+        // extra heads, sit behind unlikely branches.
+        int state = 0;      // 0 = not polled, 1 = every flag seen, 2 = fault, 3 = gave up
+        for (int g = km + (wave >> 2) * nm; g < G; g += 2 * nm) {
+            if (state == 0) {
+                // a helper's patience: ~30 us of polls (test modes: none); the primary's: the fault bound
+                const int bound = primary ? (1 << 20) : (tt ? 0 : 48);
+                state = 2;
+                for (int spin = 0; spin < bound; ++spin) {
+                    const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                    if (__all(f == want)) { state = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (!all_in && p.tail_test != 1) {      // give up - unless the give-up atomic itself finds everybody in
-                                                        // (test mode 1: the bits were all set in the prologue)
-                    // ONE lane adds (the other lanes' offsets are out of range: dropped, they return 0); helper k is the only one
-                    // that ever touches bit k between two clears, so the add never carries
-                    constexpr int kOut = 1 << 20;
-                    const unsigned old = (unsigned)__builtin_amdgcn_readfirstlane(
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1 << km, rr, lane == 0 ? 2 * 4 : kOut, 0, 0));
-                    all_in = (((old >> 8) - base) & 0xffffffu) >= (unsigned)ns;
+                if (__builtin_expect(state != 1 && !primary, 0)) {
+                    // out of patience (this WAVE: the decision needs no barrier).  An atomic OR of bit km into the ticket word:
+                    // if it returns an incomplete count the primary's ticket comes later and returns the bit - leave; if the
+                    // count is complete every workgroup is resident and the flags will come - poll on to the fault bound and
+                    // merge (the primary may have seen a bit another wave of this workgroup set: it then merges the head as
+                    // well, same values).  A bit set after the primary's clear survives into the next launch and costs its
+                    // primary one merge more, nothing else.  Test mode 1: the bits were all set in the prologue.
+                    unsigned old = 0;
+                    if (tt != 1 && lane == 0) old = __hip_atomic_fetch_or(tail_rec(p, bh) + 2, 1u << km, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                    if (tt == 1 || (((old >> 8) - (unsigned)tl[6]) & 0xffffffu) < (unsigned)ns) state = 3;
+                    else
+                        for (int spin = 0; spin < (1 << 20); ++spin) {
+                            const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                            if (__all(f == want)) { state = 1; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
                 }
-                if (lane == 0) tl[4] = all_in ? 1 : 0;
+                MILLION_STAMP(p, 11);
+                if (state == 3) break;
+                if (__builtin_expect(state == 2, 0) && lane == 0) atomicAdd(&g_tail_faults, 1u);      // this wave's outputs are written as NaN
             }
-            __syncthreads();
-            take = tl[4] != 0;
+            tail_merge_head(p, b, hk, g, wave & 3, ns, src, lane, state == 2);
         }
-        if (take) {
-            bool fault = true;
-            for (int spin = 0; spin < (1 << 20); ++spin) {      // bounded: a workgroup that never publishes must not hang the GPU
-                const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
-                if (__all(f == want)) { fault = false; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            MILLION_STAMP(p, 11);
-            if (fault && lane == 0) atomicAdd(&g_tail_faults, 1u);      // this wave's outputs are written as NaN
-            // the heads this workgroup merges: its own (km, km + nm, ...) and - the primary - those of the helpers that gave up
-            // before it took its index (bits of its own ticket).  ONE call site: the merge runs once per workgroup from a cold
-            // instruction cache, and every inlined copy more made it slower (five copies: 1.6-2.3 us from "flags seen" to the
-            // end, round 3's single copy: 1.25).  Four waves per head: waves 0-3 take the even positions of the list, 4-7 the odd.
-            unsigned hm = 0;
-            for (int g = km; g < G; g += nm) hm |= 1u << g;
-            if (primary && nm > 1) {
-                const unsigned gave = (unsigned)tl[5] & ((1u << (nm - 1)) - 1u);
-                for (int h = 0; h < nm - 1; ++h)
-                    if (gave >> h & 1u)
-                        for (int g = h; g < G; g += nm) hm |= 1u << g;
+        // the primary also merges the heads of the helpers that gave up before it took its index (bits of its own ticket):
+        // heads h, h + nm, ... of helper h, the same four-waves-per-head split
+        const unsigned gave = primary ? (unsigned)tl[5] & ((1u << (nm - 1)) - 1u) : 0u;
+        if (__builtin_expect(gave != 0, 0)) {
+            if (state == 0) {      // waves 4-7 of a primary with one head of its own have not polled yet
+                state = 2;
+                for (int spin = 0; spin < (1 << 20); ++spin) {
+                    const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(rf, fo, 0, 16);
+                    if (__all(f == want)) { state = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (state == 2 && lane == 0) atomicAdd(&g_tail_faults, 1u);
             }
             int pos = 0;
-            for (int g = 0; g < G; ++g)
-                if (hm >> g & 1u) {
-                    if ((pos & 1) == (wave >> 2)) tail_merge_heads<1>(p, b, hk, g, 0, wave & 3, ns, src, lane, false, fault);
-                    ++pos;
-                }
+            for (int h = 0; h < nm - 1; ++h)
+                if (gave >> h & 1u)
+                    for (int g = h; g < G; g += nm) {
+                        if ((pos & 1) == (wave >> 2)) tail_merge_head(p, b, hk, g, wave & 3, ns, src, lane, state == 2);
+                        ++pos;
+                    }
         }
     }
     if (idx == ns - 1 && tid == 0) {

@@ -57,7 +57,7 @@ for i in range(2 * args.layers):
     run(i)
 torch.cuda.synchronize()
 lib.million_debug_set_stamp_buffer(stamps.data_ptr())
-spans, last = [], None
+spans, last, crit = [], None, []
 for i in range(args.layers):
     stamps.zero_()
     run(i)
@@ -65,6 +65,12 @@ for i in range(args.layers):
     s = stamps.cpu().numpy().reshape(-1, NW, NS)
     s = s[s[:, 0, 0] != 0]
     spans.append((s[:, :, 6].max() - s[:, :, 0].min()) / 100.0)
+    # the critical path of this launch: the workgroup that raises its flag last (start offset + its own time to the flag),
+    # then the merge behind it
+    t0_ = s[:, :, 0].min()
+    w = int(s[:, 0, 10].argmax())
+    crit.append(((s[w, 0, 0] - t0_) / 100.0, (s[w, 0, 10] - s[w, 0, 0]) / 100.0, (s[:, :, 6].max() - s[w, 0, 10]) / 100.0,
+                 (s[:, 0, 0].max() - t0_) / 100.0, ((s[:, 0, 10] - s[:, 0, 0]) / 100.0).mean(), ((s[:, 0, 10] - s[:, 0, 0]) / 100.0).max()))
     last = s
 lib.million_debug_set_stamp_buffer(None)
 # stamp ids in program order, and what ends at each
@@ -88,6 +94,9 @@ s = last
 t0 = s[:, :, 0].min()
 print(f"workgroups {s.shape[0]}; kernel span (first start -> last end) per launch [us]: {[round(float(x), 2) for x in spans]}")
 print("start skew of workgroups [us]: max %.2f" % ((s[:, 0, 0].max() - t0) / 100.0))
+c_ = np.array(crit)
+print("critical path, mean over the %d launches [us]: last flag raiser starts @%.2f, takes %.2f to its flag, the merge behind it ends %.2f later"
+      " | start skew max %.2f; start -> flag over all workgroups: mean %.2f max %.2f" % ((len(crit),) + tuple(c_.mean(0))))
 for name, sel in (("waves 0-3 (carry a residual tile at r=100, 32 splits)", s[:, :4, :].reshape(-1, NS)), ("waves 4-7", s[:, 4:, :].reshape(-1, NS))):
     print(f"--- {name}: mean time since that wave's start, and step duration [us]")
     prev = 0
