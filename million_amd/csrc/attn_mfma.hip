@@ -897,14 +897,15 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     //      for nothing itself, so its polls end under ANY dispatch order and residency.  The nm - 1 workgroups that arrived
     //      just before it are HELPERS (merger k = idx - (ns - nm) takes heads k, k + nm, ...).  A helper needs the flags of
     //      workgroups that arrived AFTER it and may not even be dispatched (more workgroups than resident slots; two launches
-    //      sharing the chip), so it first looks - with a SHORT bound - whether every workgroup has taken its index: then all
-    //      are resident and the flags will come.  If the bound runs out it GIVES UP, and the primary must know.  Both facts live
-    //      in ONE word, the ticket word of the (b, kv head): arrival count in bits 31:8 (a ticket is an atomic add of 256),
-    //      give-up bits 7:0 (an atomic add of 1 << k by helper k alone).  Atomics on one word are serialised, so a helper's give-up either precedes the
-    //      last ticket - then the primary's own ticket, fetched ~3 us before its tail, RETURNED the bit - or follows it - then
-    //      the give-up atomic returns a full count and the helper takes its heads after all.  Nobody polls anybody's status.
-    //      The count is never reset (a straggling helper of this launch must never read a count that looks incomplete): a
-    //      launch's indices are counted from `base`, which the primary moves on by ns at the end, together with the generation.
+    //      sharing the chip), so its patience is BOUNDED (48 polls of the flags, ~30 us).  What happens then is decided on ONE
+    //      word, the ticket word of the (b, kv head): arrival count in bits 31:8 (a ticket is an atomic add of 256), give-up
+    //      bits 7:0.  A helper wave out of patience ORs bit k in and looks at the count the atomic returns: incomplete - the
+    //      last ticket comes later and RETURNS the bit to the primary (fetched ~3 us before its tail): leave, the primary merges
+    //      head k too; complete - every workgroup is resident, the flags will come: poll on and merge.  Atomics on one word are
+    //      serialised, so there is no window between the two cases, and nobody polls anybody's status.  The count is never
+    //      reset (a straggling wave must never read a count that looks incomplete): a launch's indices are counted from
+    //      `base`, which the primary moves on by ns at the end, together with the generation; it also clears the bits (one set
+    //      behind the clear costs the next launch's primary a redundant merge of the same values, nothing else).
     //      (Round 3 let all nm mergers wait for flags without bound: when every resident workgroup is such a merger the launch
     //      stalls for the spin bound and merges stale partials.  The primary alone pulls all 64 KiB of a (b, kv head)'s
     //      partials through ONE CU: +1.2 us per launch at one request; helpers that report through status words the primary
