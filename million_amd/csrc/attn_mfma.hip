@@ -1622,9 +1622,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     STAMP(7);
     {
         v4u *ld = (v4u *)smem;
+        v4u *ldv = (v4u *)(smem + kVBase);
 #pragma unroll
         for (int i = 0; i < NT; ++i) ld[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabk[i];
-        v4u *ldv = (v4u *)(smem + kVBase);
 #pragma unroll
         for (int i = 0; i < NT; ++i) ldv[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabv[i];
     }
@@ -1672,6 +1672,33 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     ParA pa;
     v8f16 Acur;
     float sc[8];
+#if MILLION_EXP & 32
+    // development build "the launch without arithmetic" (tools/ab_build.py 32): every request, wait, barrier and the whole tail
+    // stay; a unit's bytes are xor-ed into a sink instead of gathered, multiplied and soft-maxed.  What this build takes at a
+    // shape is what that shape costs before the first instruction of the attention arithmetic (profiles/r04_launch_floor.txt).
+    unsigned sink = 0;
+#define SINK_V4(x) sink ^= (x)[0] ^ (x)[1] ^ (x)[2] ^ (x)[3]
+#define KG(SL, ST)                                                                                                 \
+    do {                                                                                                           \
+        if ((ST) == 0) {                                                                                           \
+            if constexpr (MS == 64) { SINK_V4(ring[SL].k[0]); SINK_V4(ring[SL].k[1]); }                            \
+            else sink ^= ring[SL].k[0][0] ^ ring[SL].k[0][1] ^ ring[SL].k[1][0] ^ ring[SL].k[1][1];                \
+        }                                                                                                          \
+    } while (0)
+#define KM(ST) (void)0
+#define VG(SL, I)                                                                                                  \
+    do {                                                                                                           \
+        if ((I) == 0) {                                                                                            \
+            SINK_V4(ring[SL].v[0]);                                                                                \
+            if constexpr (MS == 64) SINK_V4(ring[SL].v[MS == 64 ? 1 : 0]);                                         \
+        }                                                                                                          \
+    } while (0)
+#define VS(I) {}
+#define VPREP() {}
+#define SCORES_OUT(J) { _Pragma("unroll") for (int i = 0; i < 8; ++i) sc[i] = 0.f; (void)D; }
+#define SOFTMAX_RAW() (void)0
+#else
+#define SOFTMAX_RAW() softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane)
 #define KG(SL, ST) st_kgather<CL2>(ring[SL], ST, kbase, a[(ST) & 1])
 #define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
         as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
@@ -1710,6 +1737,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 sc[i] = t_u + 8 * q4 + 4 * (i >> 2) + (i & 3) < T ? D[i >> 2][i & 3] : -INFINITY;                  \
         }                                                                                                          \
     }
+#endif
     // BLOCK: the value steps of the unit in slot U4 (round J) interleaved with the 8 score stages of the unit in slot
     // U4 + 1 (round J + 1); then the first gathers of the next block, the refill of slot U4 with round J + 4 and the
     // online softmax of round J + 1.
@@ -1731,7 +1759,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         }                                                                                                          \
         UNIT_REQ_V(U4, (J) + 4)                                                                                    \
         SCORES_OUT((J) + 1)                                                                                        \
-        softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                       \
+        SOFTMAX_RAW();                                       \
         VPREP()                                                                                                    \
     }
 #define VALUE_ALONE(U4)                                                                                            \
@@ -1751,7 +1779,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             if (st + 2 < 8) KG(SL, st + 2);                                                                        \
         }                                                                                                          \
         SCORES_OUT(J)                                                                                              \
-        softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane);                                       \
+        SOFTMAX_RAW();                                       \
         VPREP()                                                                                                    \
         _Pragma("unroll") for (int k = 0; k < VD; ++k) VG(SL, k);                                                  \
         VALUE_ALONE(SL)                                                                                            \
@@ -1780,7 +1808,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 for (int i = 0; i < 8; ++i) sc[i] = -INFINITY;
             }
         }
-        softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane);
+        SOFTMAX_RAW();
         VPREP()
         STAMP(16);
         UNIT_REQ(3, 3)
@@ -1824,11 +1852,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef VS
 #undef VPREP
 #undef SCORES_OUT
+#undef SOFTMAX_RAW
 #undef BLOCK
 #undef VALUE_ALONE
 #undef UNIT_REQ
 #undef UNIT_REQ_K
 #undef UNIT_REQ_V
+#if MILLION_EXP & 32
+    if (sink == 0x9e3779b9u) sr.l += 1.f;      // never: keeps the sink (and the loads behind it) alive
+#endif
     STAMP(3);
     merge_and_publish<MS, PV>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l, treq);
 #undef STAMP
