@@ -1342,8 +1342,10 @@ def test_attn_more_workgroups_than_resident_slots(bs, cap, T, r, env, oracle):
 def test_attn_merge_helpers_give_up(bs, nh, nhk, T, r, env, oracle):
     """The split merge of the MFMA kernels: the last-arriving workgroup of a (b, kv head) is responsible for every head; the
     workgroups that arrived just before it help (one head each) when they see every split's flag within a short bound, and
-    say so in a status word.  million_set_force_generic(4) makes every helper give up at once: the last arriver must then
-    merge all heads itself - same output, no fault; and with the helpers on, the same."""
+    give up otherwise through a bit in the pair's ticket word, which the last arriver's own ticket returns.
+    million_set_force_generic(4) presets every give-up bit, (8) takes the helpers' patience away (they give up through their
+    own atomic unless every workgroup has already taken its ticket): the last arriver must then merge the heads concerned
+    itself - same output, no fault; and with the helpers on, the same."""
     torch, ops = env
     from million_amd import _lib
     c = synth.attn_case(9700 + nh + T % 31, bs, nh, nhk, 128, 64, 256, T, r)
