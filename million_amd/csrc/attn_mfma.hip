@@ -771,7 +771,8 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     const int ns = p.nslots;
     const int bh = b * p.nh_k + hk;
     // LDS words by absolute address (a generic pointer made these FLAT accesses): [1] arrival index, [2] generation,
-    // [3] 1 = every split of this (b, kv head) runs on this XCD
+    // [3] 1 = every split of this (b, kv head) runs on this XCD, [5] give-up bits as this workgroup's ticket returned them,
+    // [6] count base of this launch (common.h: record words [2] and [4])
     typedef volatile __attribute__((address_space(3))) int *lds_int_p;
     const lds_int_p tl = (lds_int_p)(size_t)kPartOff;
     // ---- census line / arrival index / generation: requested ~3 us ago by the streaming loop (tail_request); a wave that

@@ -388,3 +388,47 @@ def test_make_install_pth_resolves_bindings_without_pythonpath(tmp_path):
     assert str(root) in r.stdout
     r = subprocess.run([sys.executable, str(root / "tools" / "install_pth.py"), "--target", str(site_dir), "--uninstall"], capture_output=True, text=True)
     assert r.returncode == 0 and not (site_dir / "million_hip.pth").exists()
+
+
+def test_split_merge_ticket_word_protocol_every_interleaving():
+    """The split merge of the MFMA kernels (attn_mfma.hip "Tail", common.h record word [2]): ONE word per (b, kv head) holds the
+    arrival count (a ticket = atomic add of 256) and the give-up bits of the merge helpers (helper k: atomic OR of 1 << k).
+    A helper wave out of patience ORs its bit and leaves iff the count the atomic returns is incomplete; the primary - the
+    workgroup whose ticket completes the count - merges the heads of every helper whose bit its own ticket returned.  Model of
+    exactly that rule, run over EVERY order of the atomics of 3 helpers (each with 2 waves that may or may not run out of
+    patience) and the primary's ticket: each head must be merged by somebody - and a head the primary takes over must be one
+    whose helper may really have left.  (The atomics of one word are serialised by the memory system, so an order of the
+    atomics is all there is to enumerate; the device code is exercised by tests/test_gpu_parity.py::test_attn_merge_*.)"""
+    import itertools
+
+    ns, nm = 8, 4                       # 8 splits, 4 mergers: helpers = arrival indices 4, 5, 6; primary = 7
+    helpers = range(nm - 1)
+    checked = 0
+    # every helper wave either sees the flags in time (no atomic) or gives up (one OR somewhere in the order)
+    for gives in itertools.product([0, 1, 2], repeat=nm - 1):          # waves of helper k that run out of patience
+        events = ["ticket"] + [("or", k, w) for k in helpers for w in range(gives[k])]
+        for order in set(itertools.permutations(events)):
+            word = (ns - 1) << 8                                       # every ticket but the primary's has been taken
+            left = {k: 0 for k in helpers}                             # waves of helper k that left without merging
+            stayed = {k: 2 - gives[k] for k in helpers}                # waves that merged their part (saw the flags, or polled on)
+            seen_by_primary = 0
+            for ev in order:
+                if ev == "ticket":
+                    seen_by_primary = word & 0xFF                      # the primary's own ticket returns the bits set so far
+                    word += 256
+                else:
+                    _, k, _w = ev
+                    old, word = word, word | (1 << k)
+                    if (old >> 8) < ns:
+                        left[k] += 1                                   # incomplete count: the primary's ticket comes later
+                    else:
+                        stayed[k] += 1                                 # complete: everybody is resident, poll on and merge
+            for k in helpers:
+                primary_merges = bool(seen_by_primary >> k & 1)
+                # every part of head k is written: by the helper's waves that stayed, or - whole head - by the primary
+                assert primary_merges or left[k] == 0, (gives, order)
+                # the primary never takes over a head whose helper did not raise the bit before the last ticket
+                assert not primary_merges or left[k] > 0, (gives, order)
+                assert left[k] + stayed[k] == 2
+            checked += 1
+    assert checked > 500
