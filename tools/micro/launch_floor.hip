@@ -37,7 +37,24 @@ struct P {
 
 // FLAGS: 1 page ids through memory (else computed), 2 codebooks -> LDS, 4 tail (publish + flags + merge), 8 code loads
 template <int FLAGS>
-__global__ __launch_bounds__(kNT) void floor_kernel(P p) {
+__device__ __forceinline__ void floor_body(P p);
+template <int FLAGS>
+__global__ __launch_bounds__(kNT) void floor_kernel(P p) { floor_body<FLAGS>(p); }
+// the same kernel with its arguments passed one by one (pointers first): compiled with
+// -mllvm -amdgpu-kernarg-preload-count=16 the first 16 dwords arrive in SGPRs with the wave (no s_load round trip in front of
+// the page-id load); a struct passed by value is not preloaded
+template <int FLAGS>
+__global__ __launch_bounds__(kNT) void floor_kernel_args(const int *lengths, const int *page_ids, const unsigned char *kpool,
+                                                         const unsigned char *vpool, const u32x4 *tables, float *part, unsigned *flags,
+                                                         unsigned *cnt, unsigned short *out, unsigned *sink, int n_pages_cap,
+                                                         unsigned launch_id) {
+    P p;
+    p.lengths = lengths; p.page_ids = page_ids; p.kpool = kpool; p.vpool = vpool; p.tables = tables; p.part = part;
+    p.flags = flags; p.cnt = cnt; p.out = out; p.sink = sink; p.n_pages_cap = n_pages_cap; p.launch_id = launch_id;
+    floor_body<FLAGS>(p);
+}
+template <int FLAGS>
+__device__ __forceinline__ void floor_body(P p) {
     extern __shared__ u32x4 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,11 +141,13 @@ __global__ __launch_bounds__(kNT) void floor_kernel(P p) {
     if (idx == kNS - 1 && tid == 0) __hip_atomic_store(p.cnt + bh * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int FLAGS>
+template <int FLAGS, bool ARGS = false>
 static double run(const char *name, P p, const unsigned char *kbase, const unsigned char *vbase, size_t pool_bytes, int iters) {
     auto k = floor_kernel<FLAGS>;
+    auto ka = floor_kernel_args<FLAGS>;
     const size_t lds = 128 * 1024;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     unsigned launch = 1;
@@ -137,7 +156,9 @@ static double run(const char *name, P p, const unsigned char *kbase, const unsig
         q.kpool = kbase + (size_t)(i % 32) * pool_bytes;      // 32 "layers": 1 GB of codes in rotation beats the Infinity Cache
         q.vpool = vbase + (size_t)(i % 32) * pool_bytes;
         q.launch_id = launch++;
-        hipLaunchKernelGGL(k, dim3(kNS * kBH), dim3(kNT), lds, 0, q);
+        if (ARGS) hipLaunchKernelGGL(ka, dim3(kNS * kBH), dim3(kNT), lds, 0, q.lengths, q.page_ids, q.kpool, q.vpool, q.tables, q.part, q.flags,
+                                     q.cnt, q.out, q.sink, q.n_pages_cap, q.launch_id);
+        else hipLaunchKernelGGL(k, dim3(kNS * kBH), dim3(kNT), lds, 0, q);
     };
     for (int i = 0; i < 16; ++i) go(i);
     CK(hipDeviceSynchronize());
@@ -184,5 +205,12 @@ int main() {
     run<8 | 1 | 2 | 4>("+ tail: partial -> L2, flags, arrival counter, 4 mergers per (b, kv head)   = the launch without arithmetic", p, kpool, vpool, pool_bytes, it);
     run<2 | 4>("codebooks + tail, no codes", p, kpool, vpool, pool_bytes, it);
     run<4>("tail alone", p, kpool, vpool, pool_bytes, it);
+    // arguments one by one instead of one struct by value (see floor_kernel_args): preloaded into SGPRs when built with
+    // -mllvm -amdgpu-kernarg-preload-count=16, plain s_load otherwise
+    run<0, true>("args one by one: launch alone", p, kpool, vpool, pool_bytes, it);
+    run<8 | 1, true>("args one by one: + codes, page ids through memory", p, kpool, vpool, pool_bytes, it);
+    run<8 | 1 | 2 | 4, true>("args one by one: the launch without arithmetic", p, kpool, vpool, pool_bytes, it);
+    run<8 | 1, false>("struct again: + codes, page ids through memory", p, kpool, vpool, pool_bytes, it);
+    run<8 | 1 | 2 | 4, false>("struct again: the launch without arithmetic", p, kpool, vpool, pool_bytes, it);
     return 0;
 }
