@@ -65,6 +65,16 @@ struct UnitCodes32 {
     v4u v[1];   // V code bytes: lane (h, c): subspace m = c, tokens [16h, 16h+16)
 };
 
+// M = 16 (d_m = 8, streaming kernel only, round 4): a token's code row is 16 bytes, a codebook entry 16 bytes (one ds_read_b128)
+// - the whole A operand of a 16x16x32 k-step on the K side and the whole B operand of one on the V side (see "d_m = 8 form")
+struct UnitCodes16 {
+    unsigned k[2];   // K code bytes: score tile g2, lane (q, c): tile row c, bytes [4q, 4q+4) = subspaces 4q .. 4q+3 of that token
+    unsigned v[2];   // V code bytes: tile g2, lane (t, n): subspace n, tile rows 4t .. 4t+3 (tokens 8t + 4 g2 + 0..3 of the unit)
+};
+// accumulators of the d_m = 8 form: row tile h (dim position 4h + dq), lane (dq = lane >> 4, n = lane & 15): register i = head i,
+// dims 8n + 4h + dq
+struct Acc8 { float __attribute__((ext_vector_type(4))) t[2]; };
+
 // LDS by absolute byte address: the dynamic LDS segment of this kernel starts at 0 (no static LDS; the
 // kernel traps otherwise), so a lookup address needs no base add.
 __device__ __forceinline__ unsigned lds32(unsigned addr) {
@@ -72,6 +82,9 @@ __device__ __forceinline__ unsigned lds32(unsigned addr) {
 }
 __device__ __forceinline__ v2u lds64(unsigned addr) {
     return *(const __attribute__((address_space(3))) v2u *)(size_t)addr;
+}
+__device__ __forceinline__ v4u lds128(unsigned addr) {
+    return *(const __attribute__((address_space(3))) v4u *)(size_t)addr;
 }
 // Diagnostic stamps go to LDS (lane 0 of each wave) and are copied out at the very end of the kernel: a global
 // store per stamp would put a vmcnt(0) into the phases being timed (and a generic-pointer store a FLAT op,
@@ -503,6 +516,17 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
 #pragma unroll
         for (int s = 0; s < 4; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
     }
+    if constexpr (MS == 16) {      // d_m = 8 form: lane (t = q4, n = c16): rows 4 t + s, dims 8 n .. 8 n + 7 = the B operand of k-step s
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            bool is_new;
+            const long long off = res_row_off(p, kResRows * wave + 4 * q4 + s_, wave, rcnt, split, rstart, r_old, is_new);
+            const v4u w = *(const v4u *)((is_new ? p.v_new + (long long)bh * 128 : vr + off) + 8 * c16);
+            t.v[s_ >> 1][4 * (s_ & 1) + 0] = w[0]; t.v[s_ >> 1][4 * (s_ & 1) + 1] = w[1];
+            t.v[s_ >> 1][4 * (s_ & 1) + 2] = w[2]; t.v[s_ >> 1][4 * (s_ & 1) + 3] = w[3];
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         bool is_new;
@@ -706,6 +730,57 @@ __device__ __forceinline__ float wave_sum_valu(float x) {
     return rows_sum(x);
 }
 
+// ---- d_m = 8 form (M = 16, streaming kernel, G <= 4; round 4) ----------------------------------------------------------
+// A 16-byte codebook entry is 8 dims of ONE token and ONE subspace: exactly one lane's 8 reduction slots of a 16x16x32 operand.
+//   scores: A[row = token][k = (quarter q4, dim 8)] = the gathered K entry of subspace 4 q4 + s in k-step s; B = the query heads,
+//           REPLICATED over the four column groups (column c = 4 dq + g holds head g): the score tile then has head g's
+//           probabilities in every lane row the value operand wants them in - no lane movement at all;
+//   values: the reduction index is (token t of 4, dim position dp of 8): B[k = (t, dp)][col n] = the gathered V entry of subspace n
+//           and tile row 4 t + s in k-step s; A[row = (dq, g)][k = (t, dp)] = P[g][token] where dp == 4 h + dq, else 0 - two row
+//           tiles h = 0 / 1 share the two non-zero registers x, y (lane-constant masks: the probability sits in ONE half of
+//           ONE register);  D[(dq, g)][n] = out[g][8 n + 4 h + dq].
+// Per 32-token unit: 8 + 8 gathers (ds_read_b128), 8 score + 16 value MFMAs (16x16x32), 8 accumulator registers, no pack and
+// no cross-lane instruction.
+__device__ __forceinline__ void d8_masks(int lane, unsigned &mx, unsigned &my) {
+    const int dq = (lane >> 2) & 3;      // column group of this lane = dim position (mod 4) of its rows
+    mx = dq == 0 ? 0x0000ffffu : dq == 1 ? 0xffff0000u : 0u;
+    my = dq == 2 ? 0x0000ffffu : dq == 3 ? 0xffff0000u : 0u;
+}
+// one value k-step: pr = this lane's probability of tile row 4 t + s (t = lane >> 4), e = the gathered V entry
+__device__ __forceinline__ void d8_vstep(float pr, const unsigned (&e)[4], unsigned mx, unsigned my, Acc8 &O) {
+    const h2 pp = {(f16)pr, (f16)pr};
+    const unsigned w = __builtin_bit_cast(unsigned, pp), x = w & mx, y = w & my;
+    const v8f16 B = as_v8f16(e[0], e[1], e[2], e[3]);
+    O.t[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(x, y, 0u, 0u), B, O.t[0], 0, 0, 0);
+    O.t[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(0u, 0u, x, y), B, O.t[1], 0, 0, 0);
+}
+// the V gather of value step (tile g2 = i >> 2, k-step s = i & 3): vconst = V col image base | 16 n, the code byte lands in
+// address bits 15:8 (an entry row of the col image [c][m] is M * 16 = 256 bytes)
+__device__ __forceinline__ void d8_vgather(const unsigned (&vc)[2], int i, unsigned vconst, unsigned (&e)[4]) {
+    const unsigned w = vc[i >> 2];
+    const unsigned sel[4] = {0x03020400u, 0x03020500u, 0x03020600u, 0x03020700u};
+    const v4u x = lds128(__builtin_amdgcn_perm(w, vconst, sel[i & 3]));
+    e[0] = x[0]; e[1] = x[1]; e[2] = x[2]; e[3] = x[3];
+}
+// residual tile in the d_m = 8 form: pr[rho] = probability of row 4 q4 + rho = the lane's own k-step rho
+__device__ __forceinline__ void value_res_tile_d8(const ResTile &t, const float (&pr)[4], unsigned mx, unsigned my, Acc8 &O) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const unsigned e[4] = {t.v[s_ >> 1][4 * (s_ & 1) + 0], t.v[s_ >> 1][4 * (s_ & 1) + 1], t.v[s_ >> 1][4 * (s_ & 1) + 2],
+                               t.v[s_ >> 1][4 * (s_ & 1) + 3]};
+        d8_vstep(pr[s_], e, mx, my, O);
+    }
+}
+
+// rescale of the accumulators: register i belongs to head i, whose alpha sits in lane i of this lane's quad
+__device__ __forceinline__ void rescale_acc(Acc8 &O, float alpha, int, int) {
+    const float f0 = MILLION_DPP(alpha, 0x00), f1 = MILLION_DPP(alpha, 0x55), f2 = MILLION_DPP(alpha, 0xAA), f3 = MILLION_DPP(alpha, 0xFF);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { O.t[h][0] *= f0; O.t[h][1] *= f1; O.t[h][2] *= f2; O.t[h][3] *= f3; }
+}
+template <int KK>
+__device__ __forceinline__ void rescale_acc(v16f32 (&O)[2][KK], float alpha, int G, int lane) { rescale_heads<KK == 1>(O, alpha, G, lane); }
+
 // Count of merges that gave up waiting for a split's flag (million_debug_tail_faults): never non-zero unless a workgroup of the
 // launch died or the workspace was not zeroed; the heads concerned are written as NaN, never as a stale partial's sum.
 __device__ unsigned g_tail_faults = 0;
@@ -763,10 +838,9 @@ __device__ __forceinline__ void tail_merge_head(const AttnParams &p, int b, int 
     }
 }
 
-template <int MS = 64, bool PV = false>
+template <int MS = 64, bool PV = false, class ACC>
 __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *smem, int b, int hk, int split, int G, int tid,
-                                                  int lane, int wave, bool dbg_on, v16f32 (&O)[2][PV ? 1 : 2], float m_run, float l_run,
-                                                  TailReq &treq) {
+                                                  int lane, int wave, bool dbg_on, ACC &O, float m_run, float l_run, TailReq &treq) {
 #define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
     const int ns = p.nslots;
     const int bh = b * p.nh_k + hk;
@@ -795,7 +869,14 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     {
         const bool hi = lane >= 32;
         const int c32 = lane & 31;
-        if (PV) {      // parity-V tiles O[n][0]: register 4 j + rho = row 8 j + 4 hi + rho = (parity j >> 1, head 8 (j & 1) + 4 hi + rho)
+        if constexpr (MS == 16) {      // d_m = 8 form: row tile h, lane (dq = lane >> 4, n = lane & 15), register i = head i
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < G) mine[i * 128 + 8 * (lane & 15) + 4 * h + (lane >> 4)] = O.t[h][i];
+        } else
+        if constexpr (PV) {      // parity-V tiles O[n][0]: register 4 j + rho = row 8 j + 4 hi + rho = (parity j >> 1, head 8 (j & 1) + 4 hi + rho)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -806,7 +887,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                         for (int n = 0; n < 2; ++n) mine[g * 128 + 2 * (32 * n + c32) + (j >> 1)] = O[n][0][4 * j + rho];
                     }
                 }
-        } else {
+        } else if constexpr (MS != 16) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)                      // tile rows 8 j + 4 hi + rho = register 4 j + rho; j = 1: groups above 8 heads
 #pragma unroll
@@ -1312,8 +1393,8 @@ __device__ __forceinline__ void v_step(const unsigned (&e)[8], const unsigned (&
 // =====================================================================================================
 // online softmax over N new scores of this lane's column (head): updates (m_run, l_run), rescales O when a
 // running maximum moves, turns the scores into probabilities in place
-template <int N, bool PV = false>
-__device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, float &l_run, v16f32 (&O)[2][PV ? 1 : 2], int G, int lane) {
+template <int N, bool PV = false, class ACC>
+__device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, float &l_run, ACC &O, int G, int lane) {
     float mx = sc[0];
 #pragma unroll
     for (int i = 1; i < N; ++i) mx = fmaxf(mx, sc[i]);
@@ -1322,7 +1403,7 @@ __device__ __forceinline__ void softmax_online(float (&sc)[N], float &m_run, flo
     const float m_safe = m_new > -INFINITY ? m_new : 0.f;
     const float alpha = fast_exp2(m_run - m_safe);
     if (__any(m_new > m_run && m_run > -INFINITY)) {
-        rescale_heads<PV>(O, alpha, G, lane);
+        rescale_acc(O, alpha, G, lane);
     }
     float ls = 0.f;
 #pragma unroll
@@ -1360,9 +1441,8 @@ struct SoftRef {
         thr_raw = (m_ + 8.0f) * inv_c;          // -inf while nothing has been seen: the first finite score moves it
     }
 };
-template <int N, bool PV = false>
-__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float inv_c, SoftRef &st, v16f32 (&O)[2][PV ? 1 : 2],
-                                                   int G, int lane) {
+template <int N, bool PV = false, class ACC>
+__device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, float inv_c, SoftRef &st, ACC &O, int G, int lane) {
     static_assert(N == 8, "one 32-token unit: 8 scores per lane");
     float mx = max3_raw(sc[0], sc[1], sc[2]);
     mx = max3_raw(mx, sc[3], sc[4]);
@@ -1373,7 +1453,7 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
         const float m_safe = m_new > -INFINITY ? m_new : 0.f;
         const float alpha = fast_exp2(st.m - m_safe);
         if (__any(m_new > st.m && st.m > -INFINITY)) {
-            rescale_heads<PV>(O, alpha, G, lane);
+            rescale_acc(O, alpha, G, lane);
         }
         st.set(m_new, st.l * alpha, inv_c);
     }
@@ -1410,6 +1490,7 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
 template <int MS> struct StreamTypes;
 template <> struct StreamTypes<64> { typedef UnitCodes Unit; typedef unsigned E[8]; };
 template <> struct StreamTypes<32> { typedef UnitCodes32 Unit; typedef unsigned E[2][8]; };
+template <> struct StreamTypes<16> { typedef UnitCodes16 Unit; typedef unsigned E[8]; };
 
 // the K gathers of score stage st (0..7) of a unit; CL2 = log2 of the centroids per subspace (8: C = 256, 7: C = 128):
 // a subspace's row of the K row image is (4 << CL2) bytes at M = 64 and (8 << CL2) at M = 32, a stage covers 16 << CL2
@@ -1428,6 +1509,14 @@ __device__ __forceinline__ void st_kgather(const UnitCodes32 &u, int st, unsigne
     const v2u lo = lds64(base + 0 * (8u << CL2) + (((w >> sh) & 0xffu) << 3));
     const v2u hi = lds64(base + 1 * (8u << CL2) + (((w >> (sh + 8)) & 0xffu) << 3));
     a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
+}
+// M = 16: stage st = (tile st >> 2, k-step st & 3): lane quarter q4 covers subspace 4 q4 + (st & 3) - byte (st & 3) of its code
+// word - whose 16-byte entry (8 dims) IS the lane's half-row of the A operand; kbase = 4 q4 subspace rows as for the others
+template <int CL2>
+__device__ __forceinline__ void st_kgather(const UnitCodes16 &u, int st, unsigned kbase, unsigned (&a)[4]) {
+    const unsigned code = (u.k[st >> 2] >> (8 * (st & 3))) & 0xffu;
+    const v4u x = lds128(kbase + (st & 3) * (16u << CL2) + (code << 4));
+    a[0] = x[0]; a[1] = x[1]; a[2] = x[2]; a[3] = x[3];
 }
 // the V gathers of value step i (M = 64: 4 steps of 8 four-byte gathers; M = 32: 2 steps of 8 eight-byte gathers)
 __device__ __forceinline__ void st_vgather(const UnitCodes &u, int i, unsigned vconst0, unsigned vconst1, unsigned (&e)[8]) {
@@ -1456,11 +1545,12 @@ template <int MS, int MODE, int CL2 = 8>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) {
     typedef typename StreamTypes<MS>::Unit Unit;
     typedef typename StreamTypes<MS>::E EBuf;
-    constexpr int kLog2M = MS == 64 ? 6 : 5;
+    constexpr int kLog2M = MS == 64 ? 6 : MS == 32 ? 5 : 4;
     constexpr bool PV = MS == 64;              // parity-V value product (see "parity-V" above); M = 32 keeps the packed form
-    constexpr int NV = PV ? 8 : 2;             // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1)
+    constexpr bool D8 = MS == 16;              // d_m = 8 form (see "d_m = 8 form" above): G <= 4, query heads replicated over the column groups
+    constexpr int NV = (PV || D8) ? 8 : 2;     // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1; D8: tile i >> 2, k-step i & 3)
     constexpr int SPV = 8 / NV;                // score stages that ride along with one value step
-    constexpr int VD = PV ? 2 : 1;             // value steps the V gathers run ahead of their MFMA (a parity-V step is 4 gathers +
+    constexpr int VD = (PV || D8) ? 2 : 1;     // value steps the V gathers run ahead of their MFMA (a parity-V step is 4 gathers +
                                                // 1 MFMA, ~100 cycles of issue: one step ahead does not cover an LDS round trip)
     constexpr int NT = 8 >> (8 - CL2);         // 16-byte pieces of a codebook image per thread (C = 256: 64 KiB, C = 128: 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1515,11 +1605,12 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     v8f16 qb[4];
     {
-        const f16 *qv = p.q + ((long long)b * p.nh + head0(p, hk) + (c16 < G ? c16 : 0)) * 128 + 32 * q4;
+        const int hq = D8 ? (c16 & 3) : c16;      // D8: column 4 dq + g holds head g (four copies of every head)
+        const f16 *qv = p.q + ((long long)b * p.nh + head0(p, hk) + (hq < G ? hq : 0)) * 128 + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             v4u t = *(const v4u *)(qv + 8 * s);
-            if (c16 >= G) t = v4u{0, 0, 0, 0};
+            if (hq >= G) t = v4u{0, 0, 0, 0};
             qb[s] = __builtin_bit_cast(v8f16, t);
         }
     }
@@ -1564,10 +1655,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // ---- one unit's 16-byte requests into ring slot SL; J is wave-uniform; rounds past the wave's last unit
     //      re-request that unit (L2 hits, never consumed), so that no code load sits in a conditional ----
     Unit ring[kRing];
-    typedef typename std::conditional<MS == 64, gptr_v4u, gptr_v2u>::type KPtr;      // global address space: no FLAT loads
+    typedef const __attribute__((address_space(1))) unsigned *gptr_u32;
+    typedef typename std::conditional<D8, gptr_u32, gptr_v4u>::type VPtr;
+    typedef typename std::conditional<MS == 64, gptr_v4u, typename std::conditional<MS == 32, gptr_v2u, gptr_u32>::type>::type KPtr;      // global address space: no FLAT loads
     const int krow0 = stream_token_of_row(0, c16);                                      // token of tile row c16 (tile 1: + 4)
     const unsigned k_lane_off = ((unsigned)krow0 << kLog2M) + (unsigned)(MS / 4) * q4;  // that token's code row, quarter q4
-    const unsigned v_lane_off = ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
+    const unsigned v_lane_off = D8 ? ((unsigned)(lane & 15) << p.ps_shift) + 8u * (lane >> 4)     // subspace row n, tile rows 4 t ..: tokens 8 t + 4 g2 + 0..3
+                                   : ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
 #define UNIT_REQ_K(SL, J)                                                                                          \
     {                                                                                                              \
         const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
@@ -1590,13 +1684,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
         const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
         const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + p.ps_shift)) + tin);                         \
-        ring[SL].v[0] = *(gptr_v4u)(vb_ + v_lane_off);                                                             \
-        if (MS == 64) ring[SL].v[MS == 64 ? 1 : 0] = *(gptr_v4u)(vb_ + v_lane_off + (32u << p.ps_shift));          \
+        if constexpr (D8) {                                                                                        \
+            ring[SL].v[0] = *(gptr_u32)(vb_ + v_lane_off);                                                         \
+            ring[SL].v[1] = *(gptr_u32)(vb_ + v_lane_off + 4u);                                                    \
+        } else {                                                                                                   \
+            ring[SL].v[0] = *(VPtr)(vb_ + v_lane_off);                                                             \
+            if (MS == 64) ring[SL].v[MS == 64 ? 1 : 0] = *(VPtr)(vb_ + v_lane_off + (32u << p.ps_shift));          \
+        }                                                                                                          \
     }
 #define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
     UNIT_REQ(0, 0)
     UNIT_REQ(1, 1)
-#if MILLION_EXP & 1
+#if (MILLION_EXP & 1)
+    if constexpr (!D8)
     // A/B: TOUCH the lines of rounds 2 and 3 (one dword per 128-byte line, result never read): the real requests of those
     // rounds go out ~2-3 us later and should then find their lines on the way or in L2
     if (p.ps_shift == 6 && k_paged) {
@@ -1634,13 +1734,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     STAMP(1);
 
     float m_run = -INFINITY, l_run = 0.f;
-    v16f32 O[2][PV ? 1 : 2];      // parity-V: one 32 x 32 tile per subspace half
+    // parity-V: one 32 x 32 tile per subspace half; d_m = 8 form: two 16 x 16 row tiles
+    typename std::conditional<D8, Acc8, v16f32[2][PV ? 1 : 2]>::type O;
+    if constexpr (D8) {
+        O.t[0] = v4f32{0.f, 0.f, 0.f, 0.f};
+        O.t[1] = v4f32{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int kk = 0; kk < (PV ? 1 : 2); ++kk)
+            for (int kk = 0; kk < (PV ? 1 : 2); ++kk)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
+                for (int i = 0; i < 16; ++i) O[n][kk][i] = 0.f;
+    }
     if (append_wave) {
         int row_n = rstart + r_old;
         row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
@@ -1650,21 +1756,25 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     unsigned sel_lo, sel_hi;      // parity-V: where a probability goes in this lane's A-operand registers
     par_selectors(lane, sel_lo, sel_hi);
+    unsigned d8mx, d8my;          // d_m = 8 form: the half of the A-operand registers this lane's rows take their probability in
+    d8_masks(lane, d8mx, d8my);
     if (has_res) {      // residual tile of this wave first: it needs neither codebook
         float scr[4];
         score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
         softmax_online<4, PV>(scr, m_run, l_run, O, G, lane);
-        if constexpr (PV) value_res_tile_par(rt, scr, sel_lo, sel_hi, O);
+        if constexpr (D8) value_res_tile_d8(rt, scr, d8mx, d8my, O);
+        else if constexpr (PV) value_res_tile_par(rt, scr, sel_lo, sel_hi, O);
         else value_res_tile(rt, scr, O);
     }
     STAMP(2);
     const float inv_c = 1.0f / p.scale_log2e;
     SoftRef sr;
-    sr.idle = c16 < G ? 0.f : -INFINITY;
+    sr.idle = (D8 ? (c16 & 3) : c16) < G ? 0.f : -INFINITY;
     sr.set(m_run, l_run, inv_c);
 
     const unsigned kbase = (unsigned)q4 * (64u << CL2);      // quarter q4 of the K row image: its 16 (M = 64) / 8 (M = 32) subspaces
-    const unsigned vconst0 = (unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3));
+    const unsigned vconst0 = D8 ? ((unsigned)kVBase | ((unsigned)(lane & 15) << 4))      // V col image base | 16 n (entries of 16 bytes)
+                                : ((unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3)));
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);      // M = 64 only
 
     unsigned a[2][4], P[4];
@@ -1673,6 +1783,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     ParA pa;
     v8f16 Acur;
     float sc[8];
+    float pv8[8];       // d_m = 8 form: the probabilities of the unit whose value steps are running (sc is the next unit's by then)
 #if MILLION_EXP & 32
     // development build "the launch without arithmetic" (tools/ab_build.py 32): every request, wait, barrier and the whole tail
     // stay; a unit's bytes are xor-ed into a sink instead of gathered, multiplied and soft-maxed.  What this build takes at a
@@ -1683,15 +1794,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     do {                                                                                                           \
         if ((ST) == 0) {                                                                                           \
             if constexpr (MS == 64) { SINK_V4(ring[SL].k[0]); SINK_V4(ring[SL].k[1]); }                            \
-            else sink ^= ring[SL].k[0][0] ^ ring[SL].k[0][1] ^ ring[SL].k[1][0] ^ ring[SL].k[1][1];                \
+            else if constexpr (MS == 32) sink ^= ring[SL].k[0][0] ^ ring[SL].k[0][1] ^ ring[SL].k[1][0] ^ ring[SL].k[1][1]; \
+            else sink ^= ring[SL].k[0] ^ ring[SL].k[1];                                                            \
         }                                                                                                          \
     } while (0)
 #define KM(ST) (void)0
 #define VG(SL, I)                                                                                                  \
     do {                                                                                                           \
         if ((I) == 0) {                                                                                            \
-            SINK_V4(ring[SL].v[0]);                                                                                \
-            if constexpr (MS == 64) SINK_V4(ring[SL].v[MS == 64 ? 1 : 0]);                                         \
+            if constexpr (D8) sink ^= ring[SL].v[0] ^ ring[SL].v[1];                                               \
+            else {                                                                                                 \
+                SINK_V4(ring[SL].v[0]);                                                                            \
+                if constexpr (MS == 64) SINK_V4(ring[SL].v[MS == 64 ? 1 : 0]);                                     \
+            }                                                                                                      \
         }                                                                                                          \
     } while (0)
 #define VS(I) {}
@@ -1707,12 +1822,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // moved on in place (value_next_step), and then serves both s = 1 steps
 #define VG(SL, I)                                                                                                  \
     do {                                                                                                           \
-        if constexpr (PV) v_gather_par(ring[SL].v, (I) >> 1, (I) & 1, vconst0, vconst1, e4[(I) & 3]);              \
+        if constexpr (D8) d8_vgather(ring[SL].v, (I), vconst0, e4[(I) & 3]);                                       \
+        else if constexpr (PV) v_gather_par(ring[SL].v, (I) >> 1, (I) & 1, vconst0, vconst1, e4[(I) & 3]);         \
         else st_vgather(ring[SL], (I), vconst0, vconst1, e[(I) & 1]);                                              \
     } while (0)
 #define VS(I)                                                                                                      \
     {                                                                                                              \
-        if constexpr (PV) {                                                                                        \
+        if constexpr (D8) {                                                                                        \
+            d8_vstep(pv8[(I)], e4[(I) & 3], d8mx, d8my, O);                                                        \
+        } else if constexpr (PV) {                                                                                 \
             if (((I) & 1) == 0) Acur = value_A_par(pa, (I) >> 1, sel_lo, sel_hi);                                  \
             O[(I) & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                                \
                 Acur, as_v8f16(e4[(I) & 3][0], e4[(I) & 3][1], e4[(I) & 3][2], e4[(I) & 3][3]), O[(I) & 1][0], 0, 0, 0); \
@@ -1723,7 +1841,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
 #define VPREP()                                                                                                    \
     {                                                                                                              \
-        if constexpr (PV) value_prep_par(sc, pa);                                                                  \
+        if constexpr (D8) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) pv8[i_] = sc[i_]; }                   \
+        else if constexpr (PV) value_prep_par(sc, pa);                                                             \
         else value_prep(sc, P);                                                                                    \
     }
     // raw scores of round J out of the accumulators; only the unit that holds token T - 1 (wave-uniform) is masked; a
@@ -1883,6 +2002,8 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 bool attn_mfma_shape_ok(const AttnParams &p) {
+    if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head, C = 256
+        return p.C == 256 && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
     return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxGMfma && p.rcap <= 4 * kNW * kResRows;
 }
 
@@ -1938,6 +2059,7 @@ static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T
 
 // C = 128 runs on the streaming kernel only: without it (T = 0, more than 1M tokens) the call goes back to the caller
 bool attn_mfma_handles(const AttnParams &p) {
+    if (p.M == 16) return attn_mfma_supported(p) && g_mfma_policy == 0 && mfma_stream_ok(p, mfma_splits(p));      // streaming kernel or not at all
     return attn_mfma_supported(p) && (p.C != 128 || mfma_stream_ok(p, mfma_splits(p)));
 }
 // the call will run the STREAMING kernel (not the grouped fallback): million_attn_kernel_kind
@@ -1976,12 +2098,21 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
     const dim3 grid(ns, bh), block(kNW * 64);
+    if (p.M == 16) {       // d_m = 8 form: the streaming kernel or the tile kernel (the caller's next choice)
+        if (!stream_ok || g_mfma_policy != 0) return kAttnNotHandled;
+        if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<16, 0>), grid, block, kLdsBytes, s, p);
+        else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<16, 1>), grid, block, kLdsBytes, s, p);
+        else hipLaunchKernelGGL((attn_stream_kernel<16, 2>), grid, block, kLdsBytes, s, p);
+    } else
     if (p.C == 128) {      // 128 centroids per subspace (reference setup.py:15): streaming kernel by run-time layout flags only
         if (!stream_ok) return kAttnNotHandled;      // T = 0 or more than 64 rounds per wave: the caller takes the generic kernel
         if (p.M == 64) hipLaunchKernelGGL((attn_stream_kernel<64, 2, 7>), grid, block, kLdsBytes, s, p);
