@@ -71,8 +71,15 @@ struct UnitCodes16 {
     unsigned k[2];   // K code bytes: score tile g2, lane (q, c): tile row c, bytes [4q, 4q+4) = subspaces 4q .. 4q+3 of that token
     unsigned v[2];   // V code bytes: tile g2, lane (t, n): subspace n, tile rows 4t .. 4t+3 (tokens 8t + 4 g2 + 0..3 of the unit)
 };
+// M = 32 in the d_m = 4 form (streaming kernel, G <= 4, round 4): K bytes as UnitCodes32; V bytes as in UnitCodes16, for the two
+// column tiles (subspaces n and n + 16)
+struct UnitCodes32D {
+    v2u k[2];             // as UnitCodes32
+    unsigned v[2][2];     // V code bytes: tile g2, column tile j, lane (t, n): subspace n + 16 j, tile rows 4t .. 4t+3
+};
 // accumulators of the d_m = 8 form: row tile h (dim position 4h + dq), lane (dq = lane >> 4, n = lane & 15): register i = head i,
 // dims 8n + 4h + dq
+// (d_m = 4 form: column tile j, lane (dq, n): register i = head i, dims 4 (n + 16 j) + dq)
 struct Acc8 { float __attribute__((ext_vector_type(4))) t[2]; };
 
 // LDS by absolute byte address: the dynamic LDS segment of this kernel starts at 0 (no static LDS; the
@@ -516,6 +523,23 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
 #pragma unroll
         for (int s = 0; s < 4; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
     }
+    if constexpr (MS == 320) {     // d_m = 4 form: lane (t = q4, n = c16): k-step s_: rows 4 t + 2 s_ (+ 1), dims 4 (n + 16 j) .. + 3
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                bool is_new;
+                const long long off = res_row_off(p, kResRows * wave + 4 * q4 + 2 * s_ + rr, wave, rcnt, split, rstart, r_old, is_new);
+                const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 4 * c16;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const v2u w = *(const v2u *)(vp + 64 * j);
+                    t.v[s_][4 * j + 2 * rr + 0] = w[0];
+                    t.v[s_][4 * j + 2 * rr + 1] = w[1];
+                }
+            }
+        return;
+    }
     if constexpr (MS == 16) {      // d_m = 8 form: lane (t = q4, n = c16): rows 4 t + s, dims 8 n .. 8 n + 7 = the B operand of k-step s
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
@@ -772,6 +796,36 @@ __device__ __forceinline__ void value_res_tile_d8(const ResTile &t, const float 
     }
 }
 
+// ---- d_m = 4 form (M = 32, G <= 4): the same idea with 8-byte entries.  A lane's 8 reduction slots are TWO tokens x 4 dim
+// positions: k-step s of a 16-token tile takes tile rows 4 t + 2 s and 4 t + 2 s + 1 (t = lane >> 4) - registers 2 s, 2 s + 1 of the
+// lane's own scores; the B operand is the two gathered entries of those rows, for subspace n (column tile 0) and n + 16 (tile 1);
+// rows = (dim position dq, head g): ONE row tile.  Per unit: 16 + 16 gathers (ds_read_b64), 8 + 8 MFMAs (16x16x32), 8
+// accumulator registers (the packed form: 8 + 8 MFMAs of which the value ones are 32x32x16, 48 pack v_perm, 64 accumulators).
+__device__ __forceinline__ void d4_vstep(float p0, float p1, const unsigned (&e)[8], unsigned mx, unsigned my, Acc8 &O) {
+    const h2 a0 = {(f16)p0, (f16)p0}, a1 = {(f16)p1, (f16)p1};
+    const unsigned w0 = __builtin_bit_cast(unsigned, a0), w1 = __builtin_bit_cast(unsigned, a1);
+    const v8f16 A = as_v8f16(w0 & mx, w0 & my, w1 & mx, w1 & my);
+    O.t[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, as_v8f16(e[0], e[1], e[2], e[3]), O.t[0], 0, 0, 0);
+    O.t[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, as_v8f16(e[4], e[5], e[6], e[7]), O.t[1], 0, 0, 0);
+}
+// the 4 gathers of value step i = (tile g2 = i >> 1, k-step s = i & 1): bytes 2 s, 2 s + 1 of the lane's code words of the tile;
+// vconst_j = V col image base | 8 (n + 16 j) (entries of 8 bytes, 256 bytes per code)
+__device__ __forceinline__ void d4_vgather(const unsigned (&vc)[2][2], int i, unsigned vconst0, unsigned vconst1, unsigned (&e)[8]) {
+    const unsigned sel[4] = {0x03020400u, 0x03020500u, 0x03020600u, 0x03020700u};
+    const int g2 = i >> 1, s = i & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned w = vc[g2][j], vconst = j ? vconst1 : vconst0;
+        const v2u x0 = lds64(__builtin_amdgcn_perm(w, vconst, sel[2 * s]));
+        const v2u x1 = lds64(__builtin_amdgcn_perm(w, vconst, sel[2 * s + 1]));
+        e[4 * j + 0] = x0[0]; e[4 * j + 1] = x0[1]; e[4 * j + 2] = x1[0]; e[4 * j + 3] = x1[1];
+    }
+}
+// residual tile: t.v[s][4 j + ..] = (row 4 t + 2 s, row 4 t + 2 s + 1) x dims 4 (n + 16 j) .. + 3
+__device__ __forceinline__ void value_res_tile_d4(const ResTile &t, const float (&pr)[4], unsigned mx, unsigned my, Acc8 &O) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) d4_vstep(pr[2 * s_], pr[2 * s_ + 1], t.v[s_], mx, my, O);
+}
 // rescale of the accumulators: register i belongs to head i, whose alpha sits in lane i of this lane's quad
 __device__ __forceinline__ void rescale_acc(Acc8 &O, float alpha, int, int) {
     const float f0 = MILLION_DPP(alpha, 0x00), f1 = MILLION_DPP(alpha, 0x55), f2 = MILLION_DPP(alpha, 0xAA), f3 = MILLION_DPP(alpha, 0xFF);
@@ -869,6 +923,13 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     {
         const bool hi = lane >= 32;
         const int c32 = lane & 31;
+        if constexpr (MS == 320) {     // d_m = 4 form: column tile j, lane (dq = lane >> 4, n = lane & 15), register i = head i
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < G) mine[i * 128 + 4 * ((lane & 15) + 16 * j) + (lane >> 4)] = O.t[j][i];
+        } else
         if constexpr (MS == 16) {      // d_m = 8 form: row tile h, lane (dq = lane >> 4, n = lane & 15), register i = head i
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -887,7 +948,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                         for (int n = 0; n < 2; ++n) mine[g * 128 + 2 * (32 * n + c32) + (j >> 1)] = O[n][0][4 * j + rho];
                     }
                 }
-        } else if constexpr (MS != 16) {
+        } else if constexpr (MS != 16 && MS != 320) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)                      // tile rows 8 j + 4 hi + rho = register 4 j + rho; j = 1: groups above 8 heads
 #pragma unroll
@@ -1491,6 +1552,7 @@ template <int MS> struct StreamTypes;
 template <> struct StreamTypes<64> { typedef UnitCodes Unit; typedef unsigned E[8]; };
 template <> struct StreamTypes<32> { typedef UnitCodes32 Unit; typedef unsigned E[2][8]; };
 template <> struct StreamTypes<16> { typedef UnitCodes16 Unit; typedef unsigned E[8]; };
+template <> struct StreamTypes<320> { typedef UnitCodes32D Unit; typedef unsigned E[8]; };      // M = 32, d_m = 4 form
 
 // the K gathers of score stage st (0..7) of a unit; CL2 = log2 of the centroids per subspace (8: C = 256, 7: C = 128):
 // a subspace's row of the K row image is (4 << CL2) bytes at M = 64 and (8 << CL2) at M = 32, a stage covers 16 << CL2
@@ -1504,6 +1566,14 @@ __device__ __forceinline__ void st_kgather(const UnitCodes &u, int st, unsigned 
 }
 template <int CL2>
 __device__ __forceinline__ void st_kgather(const UnitCodes32 &u, int st, unsigned kbase, unsigned (&a)[4]) {
+    const unsigned w = u.k[st >> 2][(st & 3) >> 1], base = kbase + (st & 3) * (16u << CL2);
+    const unsigned sh = 16 * (st & 1);
+    const v2u lo = lds64(base + 0 * (8u << CL2) + (((w >> sh) & 0xffu) << 3));
+    const v2u hi = lds64(base + 1 * (8u << CL2) + (((w >> (sh + 8)) & 0xffu) << 3));
+    a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
+}
+template <int CL2>
+__device__ __forceinline__ void st_kgather(const UnitCodes32D &u, int st, unsigned kbase, unsigned (&a)[4]) {      // as UnitCodes32
     const unsigned w = u.k[st >> 2][(st & 3) >> 1], base = kbase + (st & 3) * (16u << CL2);
     const unsigned sh = 16 * (st & 1);
     const v2u lo = lds64(base + 0 * (8u << CL2) + (((w >> sh) & 0xffu) << 3));
@@ -1541,14 +1611,17 @@ __device__ __forceinline__ void st_vstep(const unsigned (&e)[2][8], const unsign
     v_step(e[1], Ps, O[1]);      // dims 4m + 2, 3
 }
 
-template <int MS, int MODE, int CL2 = 8>
+template <int MSX, int MODE, int CL2 = 8>      // MSX = M, or 320 = M 32 in the d_m = 4 form
 __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) {
-    typedef typename StreamTypes<MS>::Unit Unit;
-    typedef typename StreamTypes<MS>::E EBuf;
+    constexpr int MS = MSX == 320 ? 32 : MSX;
+    constexpr bool D4 = MSX == 320;            // M = 32, d_m = 4 form (see "d_m = 4 form" above): G <= 4, replicated query heads
+    typedef typename StreamTypes<MSX>::Unit Unit;
+    typedef typename StreamTypes<MSX>::E EBuf;
     constexpr int kLog2M = MS == 64 ? 6 : MS == 32 ? 5 : 4;
     constexpr bool PV = MS == 64;              // parity-V value product (see "parity-V" above); M = 32 keeps the packed form
     constexpr bool D8 = MS == 16;              // d_m = 8 form (see "d_m = 8 form" above): G <= 4, query heads replicated over the column groups
-    constexpr int NV = (PV || D8) ? 8 : 2;     // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1; D8: tile i >> 2, k-step i & 3)
+    constexpr int NV = (PV || D8) ? 8 : D4 ? 4 : 2;      // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1; D8: tile i >> 2,
+                                               // k-step i & 3; D4: tile i >> 1, k-step i & 1)
     constexpr int SPV = 8 / NV;                // score stages that ride along with one value step
     constexpr int VD = (PV || D8) ? 2 : 1;     // value steps the V gathers run ahead of their MFMA (a parity-V step is 4 gathers +
                                                // 1 MFMA, ~100 cycles of issue: one step ahead does not cover an LDS round trip)
@@ -1605,7 +1678,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     v8f16 qb[4];
     {
-        const int hq = D8 ? (c16 & 3) : c16;      // D8: column 4 dq + g holds head g (four copies of every head)
+        const int hq = (D8 || D4) ? (c16 & 3) : c16;      // D8: column 4 dq + g holds head g (four copies of every head)
         const f16 *qv = p.q + ((long long)b * p.nh + head0(p, hk) + (hq < G ? hq : 0)) * 128 + 32 * q4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1650,17 +1723,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
     ResTile rt;
-    if (has_res) load_res_tile<MS>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+    if (has_res) load_res_tile<MSX>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
 
     // ---- one unit's 16-byte requests into ring slot SL; J is wave-uniform; rounds past the wave's last unit
     //      re-request that unit (L2 hits, never consumed), so that no code load sits in a conditional ----
     Unit ring[kRing];
     typedef const __attribute__((address_space(1))) unsigned *gptr_u32;
-    typedef typename std::conditional<D8, gptr_u32, gptr_v4u>::type VPtr;
+    typedef typename std::conditional<D8 || D4, gptr_u32, gptr_v4u>::type VPtr;
     typedef typename std::conditional<MS == 64, gptr_v4u, typename std::conditional<MS == 32, gptr_v2u, gptr_u32>::type>::type KPtr;      // global address space: no FLAT loads
     const int krow0 = stream_token_of_row(0, c16);                                      // token of tile row c16 (tile 1: + 4)
     const unsigned k_lane_off = ((unsigned)krow0 << kLog2M) + (unsigned)(MS / 4) * q4;  // that token's code row, quarter q4
-    const unsigned v_lane_off = D8 ? ((unsigned)(lane & 15) << p.ps_shift) + 8u * (lane >> 4)     // subspace row n, tile rows 4 t ..: tokens 8 t + 4 g2 + 0..3
+    const unsigned v_lane_off = (D8 || D4) ? ((unsigned)(lane & 15) << p.ps_shift) + 8u * (lane >> 4)     // subspace row n, tile rows 4 t ..: tokens 8 t + 4 g2 + 0..3
                                    : ((unsigned)(lane & 31) << p.ps_shift) + 16u * (lane >> 5);   // subspace row, 16-token half
 #define UNIT_REQ_K(SL, J)                                                                                          \
     {                                                                                                              \
@@ -1687,6 +1760,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         if constexpr (D8) {                                                                                        \
             ring[SL].v[0] = *(gptr_u32)(vb_ + v_lane_off);                                                         \
             ring[SL].v[1] = *(gptr_u32)(vb_ + v_lane_off + 4u);                                                    \
+        } else if constexpr (D4) {                                                                                 \
+            _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                   \
+                    ring[SL].v[g2][j_] = *(gptr_u32)(vb_ + v_lane_off + 4u * g2 + ((16u * j_) << p.ps_shift));     \
         } else {                                                                                                   \
             ring[SL].v[0] = *(VPtr)(vb_ + v_lane_off);                                                             \
             if (MS == 64) ring[SL].v[MS == 64 ? 1 : 0] = *(VPtr)(vb_ + v_lane_off + (32u << p.ps_shift));          \
@@ -1696,7 +1773,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     UNIT_REQ(0, 0)
     UNIT_REQ(1, 1)
 #if (MILLION_EXP & 1)
-    if constexpr (!D8)
+    if constexpr (!D8 && !D4)
     // A/B: TOUCH the lines of rounds 2 and 3 (one dword per 128-byte line, result never read): the real requests of those
     // rounds go out ~2-3 us later and should then find their lines on the way or in L2
     if (p.ps_shift == 6 && k_paged) {
@@ -1735,8 +1812,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 
     float m_run = -INFINITY, l_run = 0.f;
     // parity-V: one 32 x 32 tile per subspace half; d_m = 8 form: two 16 x 16 row tiles
-    typename std::conditional<D8, Acc8, v16f32[2][PV ? 1 : 2]>::type O;
-    if constexpr (D8) {
+    typename std::conditional<D8 || D4, Acc8, v16f32[2][PV ? 1 : 2]>::type O;
+    if constexpr (D8 || D4) {
         O.t[0] = v4f32{0.f, 0.f, 0.f, 0.f};
         O.t[1] = v4f32{0.f, 0.f, 0.f, 0.f};
     } else {
@@ -1763,17 +1840,19 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
         softmax_online<4, PV>(scr, m_run, l_run, O, G, lane);
         if constexpr (D8) value_res_tile_d8(rt, scr, d8mx, d8my, O);
+        else if constexpr (D4) value_res_tile_d4(rt, scr, d8mx, d8my, O);
         else if constexpr (PV) value_res_tile_par(rt, scr, sel_lo, sel_hi, O);
         else value_res_tile(rt, scr, O);
     }
     STAMP(2);
     const float inv_c = 1.0f / p.scale_log2e;
     SoftRef sr;
-    sr.idle = (D8 ? (c16 & 3) : c16) < G ? 0.f : -INFINITY;
+    sr.idle = ((D8 || D4) ? (c16 & 3) : c16) < G ? 0.f : -INFINITY;
     sr.set(m_run, l_run, inv_c);
 
     const unsigned kbase = (unsigned)q4 * (64u << CL2);      // quarter q4 of the K row image: its 16 (M = 64) / 8 (M = 32) subspaces
-    const unsigned vconst0 = D8 ? ((unsigned)kVBase | ((unsigned)(lane & 15) << 4))      // V col image base | 16 n (entries of 16 bytes)
+    const unsigned vconst0 = D4 ? ((unsigned)kVBase | ((unsigned)(lane & 15) << 3))      // V col image base | 8 n (entries of 8 bytes)
+                           : D8 ? ((unsigned)kVBase | ((unsigned)(lane & 15) << 4))      // V col image base | 16 n (entries of 16 bytes)
                                 : ((unsigned)kVBase | ((unsigned)(lane & 31) << (MS == 64 ? 2 : 3)));
     const unsigned vconst1 = (unsigned)kVBase | ((unsigned)((lane & 31) + 32) << 2);      // M = 64 only
 
@@ -1783,6 +1862,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     ParA pa;
     v8f16 Acur;
     float sc[8];
+    unsigned e5[2][8];  // d_m = 4 form: the four gathered entries of a value step (two column tiles x two tokens), one step ahead
     float pv8[8];       // d_m = 8 form: the probabilities of the unit whose value steps are running (sc is the next unit's by then)
 #if MILLION_EXP & 32
     // development build "the launch without arithmetic" (tools/ab_build.py 32): every request, wait, barrier and the whole tail
@@ -1803,6 +1883,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     do {                                                                                                           \
         if ((I) == 0) {                                                                                            \
             if constexpr (D8) sink ^= ring[SL].v[0] ^ ring[SL].v[1];                                               \
+            else if constexpr (D4) sink ^= ring[SL].v[0][0] ^ ring[SL].v[0][1] ^ ring[SL].v[1][0] ^ ring[SL].v[1][1]; \
             else {                                                                                                 \
                 SINK_V4(ring[SL].v[0]);                                                                            \
                 if constexpr (MS == 64) SINK_V4(ring[SL].v[MS == 64 ? 1 : 0]);                                     \
@@ -1823,6 +1904,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #define VG(SL, I)                                                                                                  \
     do {                                                                                                           \
         if constexpr (D8) d8_vgather(ring[SL].v, (I), vconst0, e4[(I) & 3]);                                       \
+        else if constexpr (D4) d4_vgather(ring[SL].v, (I), vconst0, vconst0 + 128u, e5[(I) & 1]);                  \
         else if constexpr (PV) v_gather_par(ring[SL].v, (I) >> 1, (I) & 1, vconst0, vconst1, e4[(I) & 3]);         \
         else st_vgather(ring[SL], (I), vconst0, vconst1, e[(I) & 1]);                                              \
     } while (0)
@@ -1830,6 +1912,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     {                                                                                                              \
         if constexpr (D8) {                                                                                        \
             d8_vstep(pv8[(I)], e4[(I) & 3], d8mx, d8my, O);                                                        \
+        } else if constexpr (D4) {                                                                                 \
+            d4_vstep(pv8[2 * (I)], pv8[2 * (I) + 1], e5[(I) & 1], d8mx, d8my, O);                                  \
         } else if constexpr (PV) {                                                                                 \
             if (((I) & 1) == 0) Acur = value_A_par(pa, (I) >> 1, sel_lo, sel_hi);                                  \
             O[(I) & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                                \
@@ -1841,7 +1925,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
 #define VPREP()                                                                                                    \
     {                                                                                                              \
-        if constexpr (D8) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) pv8[i_] = sc[i_]; }                   \
+        if constexpr (D8 || D4) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) pv8[i_] = sc[i_]; }             \
         else if constexpr (PV) value_prep_par(sc, pa);                                                             \
         else value_prep(sc, P);                                                                                    \
     }
@@ -1982,7 +2066,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     if (sink == 0x9e3779b9u) sr.l += 1.f;      // never: keeps the sink (and the loads behind it) alive
 #endif
     STAMP(3);
-    merge_and_publish<MS, PV>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l, treq);
+    merge_and_publish<MSX, PV>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, sr.m, sr.l, treq);
 #undef STAMP
 }
 
@@ -2002,8 +2086,8 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 bool attn_mfma_shape_ok(const AttnParams &p) {
-    if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head, C = 256
-        return p.C == 256 && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
+    if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head
+        return (p.C == 256 || p.C == 128) && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
     return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxGMfma && p.rcap <= 4 * kNW * kResRows;
 }
 
@@ -2024,6 +2108,8 @@ int read_tail_faults() {
 // g_tail_test (million_set_force_generic 4 / 8): the merge helpers give up at once - the last arriver's take-over path, for
 // tests: 1 = every give-up bit is set in the prologue, 2 = the helpers give up through the real path (no polls, then the atomic)
 static int g_mfma_policy = 0, g_tail_test = 0;
+// development A/B (MILLION_M32_PACKED=1): M = 32 keeps the packed form at G <= 4 too
+static const int g_mfma_form = [] { const char *e = getenv("MILLION_M32_PACKED"); return e && *e == '1' ? 1 : 0; }();
 void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 3; }
 
 // split policy: about one workgroup per CU; a split is at least 512 tokens long
@@ -2098,9 +2184,13 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<320, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<320, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<320, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
@@ -2109,7 +2199,8 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     const dim3 grid(ns, bh), block(kNW * 64);
     if (p.M == 16) {       // d_m = 8 form: the streaming kernel or the tile kernel (the caller's next choice)
         if (!stream_ok || g_mfma_policy != 0) return kAttnNotHandled;
-        if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<16, 0>), grid, block, kLdsBytes, s, p);
+        if (p.C == 128) hipLaunchKernelGGL((attn_stream_kernel<16, 2, 7>), grid, block, kLdsBytes, s, p);
+        else if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<16, 0>), grid, block, kLdsBytes, s, p);
         else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<16, 1>), grid, block, kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_stream_kernel<16, 2>), grid, block, kLdsBytes, s, p);
     } else
@@ -2122,6 +2213,10 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
             if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<64, 0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<64, 1>), grid, block, kLdsBytes, s, p);
             else hipLaunchKernelGGL((attn_stream_kernel<64, 2>), grid, block, kLdsBytes, s, p);
+        } else if (p.G <= 4 && !(g_mfma_form & 1)) {      // d_m = 4 form: query heads replicated over the column groups of the score tile
+            if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<320, 0>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<320, 1>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_stream_kernel<320, 2>), grid, block, kLdsBytes, s, p);
         } else {
             if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<32, 0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<32, 1>), grid, block, kLdsBytes, s, p);

@@ -1468,8 +1468,8 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
     gold = oracle.decode_attn(**c)
     t = _dev(torch, c)
     if T:
-        # d = 128 / M = 16 / C = 256 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4)
-        stream16 = d == 128 and M == 16 and C == 256 and nh // nhk <= 4
+        # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4)
+        stream16 = d == 128 and M == 16 and nh // nhk <= 4
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
                      v_codes=t["v_codes"]) == (2 if stream16 else 4)
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
