@@ -227,12 +227,14 @@ int million_pq_decode_attn_append(const million_attn_desc *desc, const void *q, 
 int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh_k, int n_tokens, int M,
                               int64_t v_stride_b, int64_t v_stride_h, million_stream_t stream);
 
-/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = streaming MFMA kernel (d = 128, M in {64, 32}; any batch
- * and any context up to 1M tokens per (b, kv head): calls with more than 64 rounds per wave get more splits),
+/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = streaming MFMA kernel (d = 128 with M in {64, 32}, and
+ * d = 128 / M = 16 with up to 4 query heads per kv head; any batch and any context up to 1M tokens per (b, kv head): calls with
+ * more than 64 rounds per wave get more splits),
  * 2 = the same after transposing row-major V codes into workspace scratch (one extra launch), 3 = tile MFMA kernel
- * (d = 64 with M in {16, 32, 64}; d = 128 with M = 16), 4 = the same after the transpose, 5 = the grouped MFMA kernel (the
- * streaming kernel's fallback on its shapes: no quantised token yet, or more than 1M tokens), 0 = scalar fallback
- * (anything else the descriptor allows: C not 128 / 256, paged K with row-major V, ...), -1 = bad descriptor. */
+ * (d = 64 with M in {16, 32, 64}; d = 128 with M = 16 and more than 4 query heads per kv head), 4 = the same after the
+ * transpose, 5 = the grouped MFMA kernel (the streaming kernel's fallback on its M = 64 / 32 shapes: no quantised token yet,
+ * or more than 1M tokens), 0 = scalar fallback (anything else the descriptor allows: C not 128 / 256, paged K with row-major
+ * V, ...), -1 = bad descriptor. */
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Kernel choice for A/B measurements and tests: 0 = auto (default), 1 = generic kernel only, 2 = MFMA grouped kernel
  * only (never the streaming one), 4 = auto, but the helper workgroups of the split merge give up at once (exercises the

@@ -23,6 +23,9 @@
 //   * the residual window (r <= 128 fp16 rows) is dealt round-robin to the splits and, inside a split, to its
 //     waves: each wave's rows are ONE 16-row MFMA tile (scores: A = the fp16 K rows; values: B = the fp16 V rows)
 //     that rides along with the wave's code units - no separate partial, no scalar FMA loop.
+//   * round 4: M = 16 (d_m = 8) and M = 32 at G <= 4 run the streaming kernel in the "d_m = 8 / 4 forms" (see there): the query
+//     heads are replicated over the four column groups of the score tile, a gathered codebook entry is a lane's reduction slots of
+//     a 16x16x32 operand as it stands (K: A operand, V: B operand), 8 accumulator registers, no pack and no lane movement;
 //   * two kernels share everything above and the merge tail: attn_stream_kernel (the one that runs: value steps of
 //     unit u interleaved with the score stages of unit u + 1, online softmax per unit, any split length) and
 //     attn_mfma_kernel (groups of 4 units: score pass, softmax, value pass; the fallback for T = 0 and for splits of
