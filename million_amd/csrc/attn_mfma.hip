@@ -1531,7 +1531,7 @@ __device__ __forceinline__ void softmax_online_raw(float (&sc)[N], float c, floa
 }
 
 // =====================================================================================================
-// Streaming kernel: the pipelined schedule for ANY split length, M = 64 and M = 32.
+// Streaming kernel: the pipelined schedule for ANY split length, M = 64, M = 32 and (up to 4 query heads per kv head) M = 16.
 //
 // What changed against round 1's 4-unit pipelined kernel (which it replaced):
 //   * units are dealt to (split, wave) by PAGE, strided: page (j * ppr + wave / upp) * nsplit + split goes to round j of

@@ -409,7 +409,7 @@ int million_attn_kernel_kind(const million_attn_desc *desc) {
 }
 
 // one query-head group (p.G heads per kv head from p.g0 on): 1. the streaming / grouped MFMA kernels (d = 128,
-// M in {64, 32}; up to kMaxGMfma heads); 2. the tile kernel (every other shape of the binding surface); 3. the scalar
+// M in {64, 32} with up to kMaxGMfma heads, M = 16 with up to 4); 2. the tile kernel (every other shape of the binding surface); 3. the scalar
 // kernel (both up to kMaxG heads: a bigger group the MFMA kernels hand back is split here)
 static int launch_group(const AttnParams &p, hipStream_t stream) {
     if (!g_force_generic) {
