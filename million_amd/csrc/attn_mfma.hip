@@ -1760,13 +1760,16 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
         const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
         const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + p.ps_shift)) + tin);                         \
-        if constexpr (D8) {                                                                                        \
-            ring[SL].v[0] = *(gptr_u32)(vb_ + v_lane_off);                                                         \
-            ring[SL].v[1] = *(gptr_u32)(vb_ + v_lane_off + 4u);                                                    \
+        if constexpr (D8) {      /* the two tiles' rows of a lane are 8 consecutive token bytes: one 8-byte load */  \
+            const v2u w_ = *(gptr_v2u)(vb_ + v_lane_off);                                                          \
+            ring[SL].v[0] = w_[0];                                                                                 \
+            ring[SL].v[1] = w_[1];                                                                                 \
         } else if constexpr (D4) {                                                                                 \
-            _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
-                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                   \
-                    ring[SL].v[g2][j_] = *(gptr_u32)(vb_ + v_lane_off + 4u * g2 + ((16u * j_) << p.ps_shift));     \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                     \
+                const v2u w_ = *(gptr_v2u)(vb_ + v_lane_off + ((16u * j_) << p.ps_shift));                         \
+                ring[SL].v[0][j_] = w_[0];                                                                         \
+                ring[SL].v[1][j_] = w_[1];                                                                         \
+            }                                                                                                      \
         } else {                                                                                                   \
             ring[SL].v[0] = *(VPtr)(vb_ + v_lane_off);                                                             \
             if (MS == 64) ring[SL].v[MS == 64 ? 1 : 0] = *(VPtr)(vb_ + v_lane_off + (32u << p.ps_shift));          \
