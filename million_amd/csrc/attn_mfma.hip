@@ -543,15 +543,17 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
             }
         return;
     }
-    if constexpr (MS == 16) {      // d_m = 8 form: lane (t = q4, n = c16): rows 4 t + s, dims 8 n .. 8 n + 7 = the B operand of k-step s
+    if constexpr (MS == 16) {      // d_m = 8 form: lane (t = q4, n = c16): k-step s_: rows 4 t + 2 s_ (+ 1), dims 8 n + 4 h .. + 3
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            bool is_new;
-            const long long off = res_row_off(p, kResRows * wave + 4 * q4 + s_, wave, rcnt, split, rstart, r_old, is_new);
-            const v4u w = *(const v4u *)((is_new ? p.v_new + (long long)bh * 128 : vr + off) + 8 * c16);
-            t.v[s_ >> 1][4 * (s_ & 1) + 0] = w[0]; t.v[s_ >> 1][4 * (s_ & 1) + 1] = w[1];
-            t.v[s_ >> 1][4 * (s_ & 1) + 2] = w[2]; t.v[s_ >> 1][4 * (s_ & 1) + 3] = w[3];
-        }
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                bool is_new;
+                const long long off = res_row_off(p, kResRows * wave + 4 * q4 + 2 * s_ + rr, wave, rcnt, split, rstart, r_old, is_new);
+                const v4u w = *(const v4u *)((is_new ? p.v_new + (long long)bh * 128 : vr + off) + 8 * c16);
+                t.v[s_][2 * rr + 0] = w[0]; t.v[s_][2 * rr + 1] = w[1];              // half h = 0
+                t.v[s_][4 + 2 * rr + 0] = w[2]; t.v[s_][4 + 2 * rr + 1] = w[3];      // half h = 1
+            }
         return;
     }
 #pragma unroll
@@ -762,43 +764,19 @@ __device__ __forceinline__ float wave_sum_valu(float x) {
 //   scores: A[row = token][k = (quarter q4, dim 8)] = the gathered K entry of subspace 4 q4 + s in k-step s; B = the query heads,
 //           REPLICATED over the four column groups (column c = 4 dq + g holds head g): the score tile then has head g's
 //           probabilities in every lane row the value operand wants them in - no lane movement at all;
-//   values: the reduction index is (token t of 4, dim position dp of 8): B[k = (t, dp)][col n] = the gathered V entry of subspace n
-//           and tile row 4 t + s in k-step s; A[row = (dq, g)][k = (t, dp)] = P[g][token] where dp == 4 h + dq, else 0 - two row
-//           tiles h = 0 / 1 share the two non-zero registers x, y (lane-constant masks: the probability sits in ONE half of
-//           ONE register);  D[(dq, g)][n] = out[g][8 n + 4 h + dq].
-// Per 32-token unit: 8 + 8 gathers (ds_read_b128), 8 score + 16 value MFMAs (16x16x32), 8 accumulator registers, no pack and
-// no cross-lane instruction.
+//   values: a 16-byte V entry is handled as its two 8-byte halves (dims 4 h .. 4 h + 3, h = 0 / 1) in the d_m = 4 form below: the
+//           reduction index is (token of 2, dim position of 4), B = the halves h of the two tokens' entries (two ds_read_b64), A
+//           carries the two tokens' probabilities at dim position dq (lane-constant masks), one product per half:
+//           D_h[(dq, g)][n] = out[g][8 n + 4 h + dq].  (First version: whole entries by ds_read_b128, reduction index (token of 4,
+//           dim position of 8), A = {x, y, 0, 0} / {0, 0, x, y} for the two row tiles: twice the value MFMAs, and hipcc rebuilt
+//           the zero-padded operands with 8 v_mov per step.)
+// Per 32-token unit: 8 gathers (ds_read_b128) + 16 (ds_read_b64), 8 score + 8 value MFMAs (16x16x32), 8 accumulator registers, no
+// pack and no cross-lane instruction.
 __device__ __forceinline__ void d8_masks(int lane, unsigned &mx, unsigned &my) {
     const int dq = (lane >> 2) & 3;      // column group of this lane = dim position (mod 4) of its rows
     mx = dq == 0 ? 0x0000ffffu : dq == 1 ? 0xffff0000u : 0u;
     my = dq == 2 ? 0x0000ffffu : dq == 3 ? 0xffff0000u : 0u;
 }
-// one value k-step: pr = this lane's probability of tile row 4 t + s (t = lane >> 4), e = the gathered V entry
-__device__ __forceinline__ void d8_vstep(float pr, const unsigned (&e)[4], unsigned mx, unsigned my, Acc8 &O) {
-    const h2 pp = {(f16)pr, (f16)pr};
-    const unsigned w = __builtin_bit_cast(unsigned, pp), x = w & mx, y = w & my;
-    const v8f16 B = as_v8f16(e[0], e[1], e[2], e[3]);
-    O.t[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(x, y, 0u, 0u), B, O.t[0], 0, 0, 0);
-    O.t[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(0u, 0u, x, y), B, O.t[1], 0, 0, 0);
-}
-// the V gather of value step (tile g2 = i >> 2, k-step s = i & 3): vconst = V col image base | 16 n, the code byte lands in
-// address bits 15:8 (an entry row of the col image [c][m] is M * 16 = 256 bytes)
-__device__ __forceinline__ void d8_vgather(const unsigned (&vc)[2], int i, unsigned vconst, unsigned (&e)[4]) {
-    const unsigned w = vc[i >> 2];
-    const unsigned sel[4] = {0x03020400u, 0x03020500u, 0x03020600u, 0x03020700u};
-    const v4u x = lds128(__builtin_amdgcn_perm(w, vconst, sel[i & 3]));
-    e[0] = x[0]; e[1] = x[1]; e[2] = x[2]; e[3] = x[3];
-}
-// residual tile in the d_m = 8 form: pr[rho] = probability of row 4 q4 + rho = the lane's own k-step rho
-__device__ __forceinline__ void value_res_tile_d8(const ResTile &t, const float (&pr)[4], unsigned mx, unsigned my, Acc8 &O) {
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-        const unsigned e[4] = {t.v[s_ >> 1][4 * (s_ & 1) + 0], t.v[s_ >> 1][4 * (s_ & 1) + 1], t.v[s_ >> 1][4 * (s_ & 1) + 2],
-                               t.v[s_ >> 1][4 * (s_ & 1) + 3]};
-        d8_vstep(pr[s_], e, mx, my, O);
-    }
-}
-
 // ---- d_m = 4 form (M = 32, G <= 4): the same idea with 8-byte entries.  A lane's 8 reduction slots are TWO tokens x 4 dim
 // positions: k-step s of a 16-token tile takes tile rows 4 t + 2 s and 4 t + 2 s + 1 (t = lane >> 4) - registers 2 s, 2 s + 1 of the
 // lane's own scores; the B operand is the two gathered entries of those rows, for subspace n (column tile 0) and n + 16 (tile 1);
@@ -810,6 +788,19 @@ __device__ __forceinline__ void d4_vstep(float p0, float p1, const unsigned (&e)
     const v8f16 A = as_v8f16(w0 & mx, w0 & my, w1 & mx, w1 & my);
     O.t[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, as_v8f16(e[0], e[1], e[2], e[3]), O.t[0], 0, 0, 0);
     O.t[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, as_v8f16(e[4], e[5], e[6], e[7]), O.t[1], 0, 0, 0);
+}
+// d_m = 8 form: the same value step on the two 8-byte HALVES of a 16-byte entry (row tile h = dims 4 h .. 4 h + 3 of the entry):
+// vconst = V col image base | 16 n, the halves 8 bytes apart
+__device__ __forceinline__ void d8_vgather(const unsigned (&vc)[2], int i, unsigned vconst, unsigned (&e)[8]) {
+    const unsigned sel[4] = {0x03020400u, 0x03020500u, 0x03020600u, 0x03020700u};
+    const int g2 = i >> 1, s = i & 1;
+    const unsigned w = vc[g2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const v2u x0 = lds64(__builtin_amdgcn_perm(w, vconst + 8u * h, sel[2 * s]));
+        const v2u x1 = lds64(__builtin_amdgcn_perm(w, vconst + 8u * h, sel[2 * s + 1]));
+        e[4 * h + 0] = x0[0]; e[4 * h + 1] = x0[1]; e[4 * h + 2] = x1[0]; e[4 * h + 3] = x1[1];
+    }
 }
 // the 4 gathers of value step i = (tile g2 = i >> 1, k-step s = i & 1): bytes 2 s, 2 s + 1 of the lane's code words of the tile;
 // vconst_j = V col image base | 8 (n + 16 j) (entries of 8 bytes, 256 bytes per code)
@@ -1623,10 +1614,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     constexpr int kLog2M = MS == 64 ? 6 : MS == 32 ? 5 : 4;
     constexpr bool PV = MS == 64;              // parity-V value product (see "parity-V" above); M = 32 keeps the packed form
     constexpr bool D8 = MS == 16;              // d_m = 8 form (see "d_m = 8 form" above): G <= 4, query heads replicated over the column groups
-    constexpr int NV = (PV || D8) ? 8 : D4 ? 4 : 2;      // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1; D8: tile i >> 2,
-                                               // k-step i & 3; D4: tile i >> 1, k-step i & 1)
+    constexpr int NV = PV ? 8 : (D8 || D4) ? 4 : 2;      // value steps per unit (PV: token step s = i >> 1, subspace half n = i & 1; D8 / D4: tile i >> 1,
+                                               // k-step i & 1)
     constexpr int SPV = 8 / NV;                // score stages that ride along with one value step
-    constexpr int VD = (PV || D8) ? 2 : 1;     // value steps the V gathers run ahead of their MFMA (a parity-V step is 4 gathers +
+    constexpr int VD = PV ? 2 : 1;     // value steps the V gathers run ahead of their MFMA (a parity-V step is 4 gathers +
                                                // 1 MFMA, ~100 cycles of issue: one step ahead does not cover an LDS round trip)
     constexpr int NT = 8 >> (8 - CL2);         // 16-byte pieces of a codebook image per thread (C = 256: 64 KiB, C = 128: 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1845,8 +1836,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         float scr[4];
         score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);
         softmax_online<4, PV>(scr, m_run, l_run, O, G, lane);
-        if constexpr (D8) value_res_tile_d8(rt, scr, d8mx, d8my, O);
-        else if constexpr (D4) value_res_tile_d4(rt, scr, d8mx, d8my, O);
+        if constexpr (D8 || D4) value_res_tile_d4(rt, scr, d8mx, d8my, O);
         else if constexpr (PV) value_res_tile_par(rt, scr, sel_lo, sel_hi, O);
         else value_res_tile(rt, scr, O);
     }
@@ -1909,16 +1899,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // moved on in place (value_next_step), and then serves both s = 1 steps
 #define VG(SL, I)                                                                                                  \
     do {                                                                                                           \
-        if constexpr (D8) d8_vgather(ring[SL].v, (I), vconst0, e4[(I) & 3]);                                       \
+        if constexpr (D8) d8_vgather(ring[SL].v, (I), vconst0, e5[(I) & 1]);                                       \
         else if constexpr (D4) d4_vgather(ring[SL].v, (I), vconst0, vconst0 + 128u, e5[(I) & 1]);                  \
         else if constexpr (PV) v_gather_par(ring[SL].v, (I) >> 1, (I) & 1, vconst0, vconst1, e4[(I) & 3]);         \
         else st_vgather(ring[SL], (I), vconst0, vconst1, e[(I) & 1]);                                              \
     } while (0)
 #define VS(I)                                                                                                      \
     {                                                                                                              \
-        if constexpr (D8) {                                                                                        \
-            d8_vstep(pv8[(I)], e4[(I) & 3], d8mx, d8my, O);                                                        \
-        } else if constexpr (D4) {                                                                                 \
+        if constexpr (D8 || D4) {                                                                                 \
             d4_vstep(pv8[2 * (I)], pv8[2 * (I) + 1], e5[(I) & 1], d8mx, d8my, O);                                  \
         } else if constexpr (PV) {                                                                                 \
             if (((I) & 1) == 0) Acur = value_A_par(pa, (I) >> 1, sel_lo, sel_hi);                                  \
