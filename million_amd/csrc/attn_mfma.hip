@@ -1859,7 +1859,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     v8f16 Acur;
     float sc[8];
     unsigned e5[2][8];  // d_m = 4 form: the four gathered entries of a value step (two column tiles x two tokens), one step ahead
-    float pv8[8];       // d_m = 8 form: the probabilities of the unit whose value steps are running (sc is the next unit's by then)
 #if MILLION_EXP & 32
     // development build "the launch without arithmetic" (tools/ab_build.py 32): every request, wait, barrier and the whole tail
     // stay; a unit's bytes are xor-ed into a sink instead of gathered, multiplied and soft-maxed.  What this build takes at a
@@ -1893,8 +1892,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #else
 #define SOFTMAX_RAW() softmax_online_raw<8, PV>(sc, p.scale_log2e, inv_c, sr, O, G, lane)
 #define KG(SL, ST) st_kgather<CL2>(ring[SL], ST, kbase, a[(ST) & 1])
+    // (the first k-step of a tile takes a literal zero accumulator - an inline constant of the MFMA - instead of a zeroed D: 8 v_mov
+    // per unit less)
 #define KM(ST) D[(ST) >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                              \
-        as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3], D[(ST) >> 2], 0, 0, 0)
+        as_v8f16(a[(ST) & 1][0], a[(ST) & 1][1], a[(ST) & 1][2], a[(ST) & 1][3]), qb[(ST) & 3],                   \
+        ((ST) & 3) == 0 ? v4f32{0.f, 0.f, 0.f, 0.f} : D[(ST) >> 2], 0, 0, 0)
     // value steps run token-step major: i -> st = 2n + s with s = i / (NV / 2), so that P serves both s = 0 steps, is
     // moved on in place (value_next_step), and then serves both s = 1 steps
 #define VG(SL, I)                                                                                                  \
@@ -1907,7 +1909,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #define VS(I)                                                                                                      \
     {                                                                                                              \
         if constexpr (D8 || D4) {                                                                                 \
-            d4_vstep(pv8[2 * (I)], pv8[2 * (I) + 1], e5[(I) & 1], d8mx, d8my, O);                                  \
+            d4_vstep(sc[2 * (I)], sc[2 * (I) + 1], e5[(I) & 1], d8mx, d8my, O);      /* sc: the unit's probabilities until the next SCORES_OUT */ \
         } else if constexpr (PV) {                                                                                 \
             if (((I) & 1) == 0) Acur = value_A_par(pa, (I) >> 1, sel_lo, sel_hi);                                  \
             O[(I) & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                                \
@@ -1919,7 +1921,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
 #define VPREP()                                                                                                    \
     {                                                                                                              \
-        if constexpr (D8 || D4) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) pv8[i_] = sc[i_]; }             \
+        if constexpr (D8 || D4) { }                                                                                \
         else if constexpr (PV) value_prep_par(sc, pa);                                                             \
         else value_prep(sc, P);                                                                                    \
     }
@@ -1941,7 +1943,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // online softmax of round J + 1.
 #define BLOCK(U4, J)                                                                                               \
     {                                                                                                              \
-        v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
+        v4f32 D[2];                                                 \
         UNIT_REQ_K(U4, (J) + 4)      /* the K bytes of slot U4 (round J) were consumed by the previous block */    \
         _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                           \
             VS(i)                                                                                                  \
@@ -1969,7 +1971,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // self-contained, so that the branch around it carries no pipeline state.
 #define SINGLE(SL, J)                                                                                              \
     {                                                                                                              \
-        v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                                                 \
+        v4f32 D[2];                                                 \
         KG(SL, 0);                                                                                                 \
         KG(SL, 1);                                                                                                 \
         _Pragma("unroll") for (int st = 0; st < 8; ++st) {                                                         \
@@ -1989,7 +1991,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         // prologue: the 8 score stages of round 0 (masked out when the wave has no whole round: its units are all
         // handled as single units below); round 2 is requested in between
         {
-            v4f32 D[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            v4f32 D[2];
             KG(0, 0);
             KG(0, 1);
             tail_mark_xcd(p, bh, split, wave, lane);      // this split's slot of the XCD census (see there for the placement)
