@@ -369,6 +369,50 @@ def test_fused_append(paged, use_dl, env, oracle):
         assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
 
 
+@pytest.mark.parametrize("M", [32, 16], ids=["M32-d4form", "M16-d8form"])
+@pytest.mark.parametrize("nh,nhk", [(2, 2), (4, 2), (6, 2), (8, 2), (16, 2)], ids=["G1", "G2", "G3", "G4", "G8"])
+def test_attn_replicated_head_forms(M, nh, nhk, env, oracle):
+    """The streaming kernel's d_m = 4 / d_m = 8 forms (M = 32 / 16 at up to 4 query heads per kv head: query heads replicated over
+    the column groups of the score tile, gathered V entries as the value product's B operand): every group size 1..4, paged and
+    row-major, ring start > 0, three fused-append steps with device lengths; 8 heads per kv head take the packed form (M = 32) /
+    the tile kernel (M = 16) and must agree too."""
+    torch, ops = env
+    bs, T, r0, ps, C = 2, 2500, 37, 64, 256
+    c = synth.attn_case(7700 + M + nh, bs, nh, nhk, 128, M, C, T, r0, Lt=128)
+    gold = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, M, C, ps), gold, "paged")
+    _check(_run_rowmajor(torch, ops, c, M, C), gold, "rowmajor")
+    t = _dev(torch, c)
+    desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r0, k_paged=True, v_paged=True,
+                              page_size=ps, n_pages_cap=(T + ps - 1) // ps)
+    from million_amd import _lib
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == (3 if (M == 16 and nh // nhk > 4) else 1)
+    # fused append over three steps, device lengths, ring start 100
+    kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
+    rs = np.random.RandomState(3)
+    start = 100
+    kr = torch.roll(t["k_res"], start, dims=2).contiguous()
+    vr = torch.roll(t["v_res"], start, dims=2).contiguous()
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    kc, vc = torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda()
+    lengths = torch.tensor([[T, r0, start, 0]] * bs, dtype=torch.int32, device="cuda")
+    k_hist, v_hist = c["k_res"].copy(), c["v_res"].copy()
+    r = r0
+    for step in range(3):
+        k_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        v_new = rs.standard_normal((bs, nhk, 1, 128)).astype(np.float16)
+        out = ops.pq_decode_attn(t["q"], kc, vc, kp, vp, kr, vr, 0, M=M, C=C, resid_start=start, dev_lengths=lengths,
+                                 k_new=torch.from_numpy(k_new).cuda(), v_new=torch.from_numpy(v_new).cuda(),
+                                 k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, n_tokens=T)
+        torch.cuda.synchronize()
+        k_hist[:, :, r], v_hist[:, :, r] = k_new[:, :, 0], v_new[:, :, 0]
+        r += 1
+        _check(out.cpu().numpy(), oracle.decode_attn(**dict(c, k_res=k_hist, v_res=v_hist, r=r)), f"fused append step {step}")
+    assert lengths.cpu().numpy()[:, 1].tolist() == [r] * bs
+
+
 def test_prepared_codebook_cache_is_not_keyed_on_address(env, oracle):
     """Regression: a new codebook allocated where a freed one lived must not reuse its prepared table."""
     torch, ops = env
