@@ -33,10 +33,7 @@
 #include <type_traits>
 
 #include "common.h"
-
-#ifndef MILLION_EXP
-#define MILLION_EXP 0      // development A/B switches (tools/ab_build.py); 0 in the product build
-#endif
+#include "dev_switches.h"      // MILLION_EXP (0 in the product build) and the other development A/B switches
 
 namespace million {
 
@@ -2104,8 +2101,9 @@ int read_tail_faults() {
 // g_tail_test (million_set_force_generic 4 / 8): the merge helpers give up at once - the last arriver's take-over path, for
 // tests: 1 = every give-up bit is set in the prologue, 2 = the helpers give up through the real path (no polls, then the atomic)
 static int g_mfma_policy = 0, g_tail_test = 0;
-// development A/B (MILLION_M32_PACKED=1): M = 32 keeps the packed form at G <= 4 too
-static const int g_mfma_form = [] { const char *e = getenv("MILLION_M32_PACKED"); return e && *e == '1' ? 1 : 0; }();
+// development A/B (dev_switches.h; environment MILLION_M32_PACKED=1 in a MILLION_DEV_BUILD): M = 32 keeps the packed form at G <= 4
+// too.  The constant 0 in the product build.
+static const int g_mfma_form = MILLION_DEV_M32_PACKED();
 void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 3; }
 
 // split policy: about one workgroup per CU; a split is at least 512 tokens long

@@ -28,6 +28,7 @@
 // kPF tiles ahead; page ids 2 kPF tiles ahead.  V must be in transposed pages (the reference's 10-argument row-major call
 // is transposed first, million_api.hip).
 #include "common.h"
+#include "dev_switches.h"      // MILLION_TILE_PROF (per-tile stamps) is a development switch: never in the product build
 
 namespace million {
 

@@ -31,9 +31,8 @@
 
 #include "common.h"
 
-#ifndef MILLION_EXP
-#define MILLION_EXP 0      // development ablation switches (tools/ab_build.py, tools/pf_ab.sh); 0 in the product build:
-#endif                     // 1 no exponentials, 2 no barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
+#include "dev_switches.h"  // MILLION_EXP: development ablation switches (tools/ab_build.py, tools/pf_ab.sh); 0 in the product build:
+                           // 1 no exponentials, 2 no barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
 
 namespace million {
 

@@ -451,25 +451,47 @@ def _plan_cents(plan: _Plan, key_cents, value_cents, check):
     return plan.kprep, plan.vprep
 
 
+def _plan_signature(stream, query, key_codes, value_codes, key_residuals, value_residuals, v_page_ids, page_size, M, C):
+    """Only what does NOT change from one decode step to the next is in the signature: the reference's contiguous
+    (bs, nh_k, T, M) stores change their length and their batch / head strides at every flush, so those are written into the
+    descriptor per call (round 3 keyed on them: every new T added a plan, and after 256 plans nothing was cached any more).
+    What the signature leaves out is checked per call by _check_stores_per_call."""
+    paged = v_page_ids is not None
+    return (stream, query.shape, query.dtype, query.is_contiguous(), key_codes.shape[1], key_codes.stride()[2:], key_codes.dtype,
+            value_codes.shape if paged else value_codes.stride()[2:], value_codes.dtype,
+            key_residuals.shape, key_residuals.stride(), key_residuals.dtype, value_residuals.shape, value_residuals.stride(),
+            value_residuals.dtype,
+            (v_page_ids.shape, v_page_ids.dtype, v_page_ids.is_contiguous(), page_size) if paged else None,
+            query.device.index, M, C)
+
+
+def _check_stores_per_call(query, key_codes, value_codes, T, M, paged):
+    """The T-dependent facts a cached plan cannot vouch for (the signature holds neither the stores' lengths nor their batch /
+    head extents): the key store belongs to this query batch, and a row-major value store is at least as long as the key store
+    it is read beside (million_transpose_v_codes reads T rows of it: a shorter store would be read out of bounds)."""
+    if key_codes.dim() != 4 or key_codes.shape[0] != query.shape[0] or key_codes.shape[3] != M:
+        raise RuntimeError(f"pq_decode_attn: key_codes {tuple(key_codes.shape)} do not match query batch {query.shape[0]} / M={M}")
+    if not paged:
+        if (value_codes.dim() != 4 or value_codes.shape[:2] != key_codes.shape[:2] or value_codes.shape[3] != M
+                or value_codes.shape[2] < T):
+            raise RuntimeError(f"pq_decode_attn: n_tokens exceeds value_codes (value_codes {tuple(value_codes.shape)} beside "
+                               f"key_codes {tuple(key_codes.shape)})")
+
+
 def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, key_residuals, value_residuals, r, *, M, C,
                         v_page_ids=None, page_size=0, check=None):
     """The reference's production call (row-major K codes; V row-major, or a transposed page pool with page ids) with the
     per-call host work cut to the minimum.  Falls to pq_decode_attn (full validation) on the first call of a signature and
     for anything unusual (non-contiguous query, shapes off the MFMA kernels, empty store).  check: the caller's own argument
-    checks, run on those slow-path calls only (a signature that passed them once passes them again: shapes, strides and
-    dtypes of every tensor are in the signature; the codebooks are identified by object and version)."""
+    checks, run on those slow-path calls only (a signature that passed them once passes them again: dtypes, the T-independent
+    shapes and strides of every tensor are in the signature, the codebooks are identified by object and version; the stores'
+    lengths and extents, which change at every flush, are checked on every call: _check_stores_per_call).
+    Threads: a signature (the stream is part of it) must be driven from ONE thread at a time - the plan's descriptor is written
+    per call; different streams have different plans and may be driven concurrently."""
     T = key_codes.shape[2]
     paged = v_page_ids is not None
     stream = _stream()      # part of the signature: the workspace of a plan belongs to one (device, stream)
-    # Only what does NOT change from one decode step to the next is in the signature: the reference's contiguous
-    # (bs, nh_k, T, M) stores change their batch / head strides at every flush, so those are written into the descriptor
-    # per call (round 3 keyed on them: every new T added a plan, and after 256 plans nothing was cached any more).
-    sig = (stream, query.shape, query.dtype, query.is_contiguous(), key_codes.shape[1], key_codes.stride()[2:], key_codes.dtype,
-           value_codes.shape if paged else value_codes.stride()[2:], value_codes.dtype,
-           key_residuals.shape, key_residuals.stride(), key_residuals.dtype, value_residuals.shape, value_residuals.stride(),
-           value_residuals.dtype,
-           (v_page_ids.shape, v_page_ids.dtype, v_page_ids.is_contiguous(), page_size) if paged else None,
-           query.device.index, M, C)
+    sig = _plan_signature(stream, query, key_codes, value_codes, key_residuals, value_residuals, v_page_ids, page_size, M, C)
     plan = _plans.get(sig)
     if plan is None:
         if check is not None:
@@ -501,7 +523,11 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
             plan.vc, plan.vver, plan.vprep = (None, 0, kp) if value_cents is key_cents else (weakref.ref(value_cents), value_cents._version, vp)
             _plans[sig] = plan
         return out
-    _plans.move_to_end(sig)
+    try:
+        _plans.move_to_end(sig)
+    except KeyError:      # another thread's miss path evicted this signature between the lookup and here: the plan in hand is still valid
+        pass
+    _check_stores_per_call(query, key_codes, value_codes, T, M, paged)
     if T <= 0:
         raise RuntimeError("decode_attn_planned: empty code store")      # (never cached: fast_shape needs T > 0)
     r = int(r)
@@ -550,7 +576,8 @@ def lengths_advance(dev_lengths: torch.Tensor, n_flushed: int, resid_cap: int) -
 
 def set_force_generic(on) -> None:
     """0 / False = auto, 1 / True = scalar fallback kernel only, 2 = grouped MFMA kernel instead of the streaming one, 4 = auto
-    with the merge helpers giving up at once (million_hip.h: million_set_force_generic)."""
+    with the merge helpers giving up at once (every give-up bit preset), 8 = auto with helpers that have no patience (each gives
+    up through the real atomic path) - million_hip.h: million_set_force_generic."""
     L.load().million_set_force_generic(int(on))
 
 

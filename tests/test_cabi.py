@@ -122,3 +122,50 @@ def test_ops_refuse_cpu_tensors():
     from million_amd import ops
     with pytest.raises(RuntimeError):
         ops.pq_encode(torch.zeros(1, 1, 4, 128, dtype=torch.float16), torch.zeros(64, 256, 2, dtype=torch.float16))
+
+
+def test_planned_call_checks_store_extents_on_every_call(monkeypatch):
+    """the plan signature of the reference's 10-argument call holds nothing T-dependent, so the cached
+    fast path must itself refuse a row-major value store that is shorter than the key store (million_transpose_v_codes would
+    read T rows of it), a store of another batch, or another M - on the SECOND and later calls of a signature, where
+    pq_decode_attn's full validation no longer runs.  CPU tensors: the check must fire before anything touches the library."""
+    import torch
+    from million_amd import ops
+    monkeypatch.setattr(ops, "_stream", lambda: 0)
+    bs, nh, nhk, d, M, C, T = 1, 8, 2, 128, 64, 256, 256
+    q = torch.zeros(bs, nh, 1, d, dtype=torch.float16)
+    kres = torch.zeros(bs, nhk, 128, d, dtype=torch.float16)
+    vres = torch.zeros_like(kres)
+    kc = torch.zeros(bs, nhk, T, M, dtype=torch.uint8)
+    cents = torch.zeros(M, C, d // M, dtype=torch.float16)
+
+    def call(k, v):
+        sig = ops._plan_signature(0, q, k, v, kres, vres, None, 0, M, C)
+        monkeypatch.setitem(ops._plans, sig, ops._Plan())      # "this signature has been validated once"
+        return ops.decode_attn_planned(q, k, v, cents, cents, kres, vres, 17, M=M, C=C)
+
+    same_sig = lambda v: ops._plan_signature(0, q, kc, v, kres, vres, None, 0, M, C) == ops._plan_signature(0, q, kc, kc, kres, vres, None, 0, M, C)
+    short_v = torch.zeros(bs, nhk, T - 64, M, dtype=torch.uint8)
+    assert same_sig(short_v)                       # the hazard: a shorter V store is the SAME signature
+    with pytest.raises(RuntimeError, match="n_tokens exceeds value_codes"):
+        call(kc, short_v)
+    with pytest.raises(RuntimeError, match="n_tokens exceeds value_codes"):
+        call(kc, torch.zeros(bs, nhk + 1, T, M, dtype=torch.uint8))      # other head count, same strides [2:]
+    with pytest.raises(RuntimeError, match="n_tokens exceeds value_codes"):
+        call(kc, torch.zeros(bs + 1, nhk, T, M, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="do not match query batch"):
+        k2 = torch.zeros(bs + 1, nhk, T, M, dtype=torch.uint8)
+        call(k2, k2)
+    # a plan evicted by another thread between the lookup and move_to_end is not an error (ADVICE r04, low)
+    sig = ops._plan_signature(0, q, kc, short_v, kres, vres, None, 0, M, C)
+
+    class Evicting(type(ops._plans)):
+        def get(self, key, default=None):
+            v = super().get(key, default)
+            self.pop(key, None)
+            return v
+    plans = Evicting()
+    plans[sig] = ops._Plan()
+    monkeypatch.setattr(ops, "_plans", plans)
+    with pytest.raises(RuntimeError, match="n_tokens exceeds value_codes"):      # reaches the per-call check, no KeyError
+        ops.decode_attn_planned(q, kc, short_v, cents, cents, kres, vres, 17, M=M, C=C)
