@@ -235,7 +235,7 @@ def main():
         one_step()
 
     # exactly K steps between barrier + synchronize on both sides; MAX over ranks (million_amd/sharding.py)
-    elapsed = sharding.timed_steps(counted_step, args.steps, torch.cuda.synchronize, dist if world > 1 else None)
+    elapsed, elapsed_ranks = sharding.timed_steps_per_rank(counted_step, args.steps, torch.cuda.synchronize, dist if world > 1 else None)
     value, ms_per_step = sharding.aggregate_throughput(bs, args.steps, elapsed, world)
     flushes_timed = n_flush_steps
     # for the record: one whole flush period (64 steps = 63 plain + 1 flush), the steady-state mix
@@ -325,6 +325,10 @@ def main():
     period = sorted(periods_graph)[1] if periods_graph else period_eager
     alg = algorithmic_bytes(bs, nh, nhk, T_now, r_now, d, M, C)
     achieved = alg / period / 1e9
+    # every rank's own launch period (the line's roofline is rank 0's; a slow GPU shows here and in per_rank_ms_per_step)
+    period_ranks = sharding.gather_floats(period, dist if world > 1 else None)
+    # a split merge that gave up on a partial writes NaN heads and counts itself (million_hip.h): must be 0 after the timed regions
+    tail_faults = sharding.gather_floats(float(ops.tail_faults()), dist if world > 1 else None)
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"     # written from rocprofv3 --pmc passes (see profiles/README.md)
     if pmc.exists():
@@ -350,6 +354,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (round(fp16["preallocated_sdpa_us"] / (period * 1e6), 2) if fp16 else None),
             "dtype": "f16 in/out, u8 codes, f32 accumulate", "data": "synthetic",
+            "per_rank_ms_per_step": [round(1e3 * e / args.steps, 4) for e in elapsed_ranks],
+            "tail_faults": int(sum(tail_faults)),
             "config": {"workload": f"BASELINE {cfg_name}: Llama-3.1-8B shape (32 layers, nh={nh}, nh_k={nhk}, d=128), "
                                    f"ctx {T0}, PQ M={M} nbits=8, PagedPQCache page 64 / window 128, batch {bs}/GPU; "
                                    "step = 32 x (append + flush-when-full encode + fused decode attention)",
@@ -380,6 +386,8 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "launch_us_mean": round(period * 1e6, 2),
                          "launches_timed": nl,
+                         "per_rank": {"launch_us_mean": [round(x * 1e6, 2) for x in period_ranks],
+                                      "frac": [round(alg / x / 1e9 / HBM_PEAK_GBS, 4) for x in period_ranks]},
                          "timing": ("HIP events around ONE replay of a captured hipGraph of the launches / launches (how the steps are launched); "
                                     "median of three regions" if periods_graph else
                                     "HIP events around a region of back-to-back eager launches / launches; median of three regions"),
@@ -411,6 +419,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if sum(tail_faults):
+        raise SystemExit(f"bench.py: {int(sum(tail_faults))} split merges gave up waiting for a partial (NaN heads were written): "
+                         "the numbers above are not a measurement; zero the workspace (million_workspace_init) and look for a dead workgroup")
 
 
 def gpu_fp16_baseline(torch, dev, bs, nh, nhk, d, T):
@@ -545,14 +556,18 @@ def dry_cpu(args, torch, dist, world, rank):
 
     def step():
         time.sleep(0.002 * (1 + rank))
-    elapsed = sharding.timed_steps(step, args.steps, lambda: None, dist if world > 1 else None)
+    elapsed, elapsed_ranks = sharding.timed_steps_per_rank(step, args.steps, lambda: None, dist if world > 1 else None)
     value, ms = sharding.aggregate_throughput(bs, args.steps, elapsed, world)
+    period_ranks = sharding.gather_floats(20e-6 * (1 + rank), dist if world > 1 else None)      # stands for each rank's launch period
     n = dist.get_world_size() if world > 1 else 1
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN (cpu, gloo): launcher rehearsal, not a measurement", "value": round(value, 2),
                           "unit": "tokens/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "none",
+                          "per_rank_ms_per_step": [round(1e3 * e / args.steps, 4) for e in elapsed_ranks],
+                          "roofline": {"per_rank": {"launch_us_mean": [round(x * 1e6, 2) for x in period_ranks],
+                                                    "frac": [round(34.0e6 / x / 1e9 / HBM_PEAK_GBS, 4) for x in period_ranks]}},
                           "config": {"workload": "dry-cpu", "batch_per_gpu": bs, "parallelism": f"requests x{n}",
                                      "ranks_seen": seen,
                                      "window_fill_at_start": window_fill_at_start(128, args.warmup, args.steps)}}),

@@ -14,6 +14,14 @@ uninstall:
 debug-ids:         # diagnostic variant: page ids bounds-checked in the decode-attention kernels (MILLION_HIP_LIB=million_amd/libmillion_hip_dbgids.so)
 	$(PYTHON) -m million_amd.build --debug-ids
 
+# A plain-C caller of the C ABI (no Python, no torch; reference: scripts/modeldb/bindings/Kernel_Test/main.cu:59-226):
+# prepares a codebook, encodes a prompt into pages, replays decode launches, checks codes and outputs on the host.
+ROCM ?= /opt/rocm
+cabi-bench: bindings
+	mkdir -p build
+	gcc -std=c99 -O2 -Wall -Wextra -ffp-contract=off -Iinclude -I$(ROCM)/include tools/cabi_bench.c -o build/cabi_bench \
+	    -Lmillion_amd -lmillion_hip -L$(ROCM)/lib -lamdhip64 -lm -Wl,-rpath,'$$ORIGIN/../million_amd' -Wl,-rpath,$(ROCM)/lib
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -30,6 +38,6 @@ bench:
 	$(PYTHON) bench.py
 
 clean:
-	rm -f million_amd/libmillion_hip.so million_amd/libmillion_hip_dbgids.so oracle/libpq_oracle.so
+	rm -f million_amd/libmillion_hip.so million_amd/libmillion_hip_dbgids.so oracle/libpq_oracle.so build/cabi_bench
 
-.PHONY: bindings install uninstall debug-ids oracle golden test test-gpu bench clean
+.PHONY: cabi-bench bindings install uninstall debug-ids oracle golden test test-gpu bench clean

@@ -581,5 +581,12 @@ def set_force_generic(on) -> None:
     L.load().million_set_force_generic(int(on))
 
 
+def tail_faults() -> int:
+    """million_debug_tail_faults: waits for the device and returns (and clears) the number of split merges that gave up waiting
+    for a partial since the last call (their heads were written as NaN).  0 in every healthy run; bench.py and smoke() read it
+    after their timed regions and fail on anything else.  After a non-zero answer zero the workspace again."""
+    return int(L.load().million_debug_tail_faults())
+
+
 def attn_kernel_kind(desc: L.AttnDesc) -> int:
     return L.load().million_attn_kernel_kind(ctypes.byref(desc))

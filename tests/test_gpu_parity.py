@@ -2173,3 +2173,149 @@ def test_attn_two_streams_share_the_chip(env, oracle):
     assert lib.million_debug_tail_faults() == 0
     for o, g in zip(outs, golds):
         _check(o.cpu().numpy(), g, "two streams")
+
+
+# ---------------------------------------------------------------- C ABI: error paths with real pointers, threads, the C caller ----
+def _raw_attn_call(torch, ops, L, c, M, C, **over):
+    """One million_pq_decode_attn call through ctypes with REAL device pointers; `over` tampers with single arguments."""
+    lib = L.load()
+    t = _dev(torch, c)
+    kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+    T = c["k_codes"].shape[2]
+    desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=t["k_res"].shape[1], M=M, C=C, n_tokens=T, r=c["r"],
+                              k_codes=t["k_codes"], v_codes=t["v_codes"])
+    for k in ("k_stride_h", "v_stride_b", "resid_stride_h"):
+        if k in over:
+            setattr(desc, k, over[k])
+    need = lib.million_attn_workspace_bytes(ctypes.byref(desc))
+    ws = torch.zeros(need + 64, dtype=torch.uint8, device="cuda")
+    out = torch.full_like(t["q"], float("nan"))
+    p = lambda name, x: x.data_ptr() + over.get(name + "_off", 0)
+    rc = lib.million_pq_decode_attn(ctypes.byref(desc), p("q", t["q"]), p("k_codes", t["k_codes"]), p("v_codes", t["v_codes"]), 0, 0,
+                                    p("k_prep", kp), p("v_prep", vp), p("k_res", t["k_res"]), p("v_res", t["v_res"]), p("out", out),
+                                    p("ws", ws), need + over.get("ws_bytes_delta", 0), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return rc, lib.million_last_error().decode(), out, need
+
+
+def test_cabi_error_paths_with_real_pointers(env, oracle):
+    """MILLION_ERR_WORKSPACE and MILLION_ERR_ALIGN (million_api.hip attn_impl / million_transpose_v_codes) with real device
+    pointers: a workspace one byte short, pointers moved by 2 bytes, strides that break the 16-byte rule.  The reference checks
+    nothing and exits the process on a launch error (Interface.template.cu:3-11); here every refusal is a status + a message,
+    nothing is launched (the NaN-poisoned output stays untouched) and the very next good call works."""
+    torch, ops = env
+    from million_amd import _lib as L
+    M, C = 64, 256
+    c = synth.attn_case(9901, 1, 8, 2, 128, M, C, 700, 21)
+    gold = oracle.decode_attn(**c)
+    rc, msg, out, need = _raw_attn_call(torch, ops, L, c, M, C)
+    assert rc == 0, msg
+    _check(out.cpu().numpy(), gold, "raw ctypes call")
+    rc, msg, out, _ = _raw_attn_call(torch, ops, L, c, M, C, ws_bytes_delta=-1)
+    assert rc == -4 and "workspace" in msg and str(need) in msg, (rc, msg)            # MILLION_ERR_WORKSPACE, says how much it wants
+    assert torch.isnan(out).all()
+    for name in ("q", "k_codes", "v_codes", "k_res", "v_res", "out", "ws", "k_prep", "v_prep"):
+        rc, msg, out, _ = _raw_attn_call(torch, ops, L, c, M, C, **{name + "_off": 2})
+        assert rc == -2 and "16-byte aligned" in msg, (name, rc, msg)                  # MILLION_ERR_ALIGN
+        assert torch.isnan(out).all() or name == "out"
+    for k, v, what in (("k_stride_h", 700 * 64 + 8, "code strides"), ("v_stride_b", 2 * 700 * 64 + 1, "code strides"),
+                       ("resid_stride_h", 128 * 128 + 4, "residual strides")):
+        rc, msg, out, _ = _raw_attn_call(torch, ops, L, c, M, C, **{k: v})
+        assert rc == -2 and what in msg, (k, rc, msg)
+        assert torch.isnan(out).all()
+    # the fused-append entry: k_new / v_new alignment; transpose entry: pointer and stride alignment
+    lib = L.load()
+    t = _dev(torch, c)
+    kp = ops.prepare_cents(t["k_cents"], cache=False)
+    desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=2, M=M, C=C, n_tokens=700, r=21, k_codes=t["k_codes"], v_codes=t["v_codes"])
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    new = torch.zeros(1, 2, 1, 136, dtype=torch.float16, device="cuda")
+    rc = lib.million_pq_decode_attn_append(ctypes.byref(desc), t["q"].data_ptr(), new.data_ptr() + 2, new.data_ptr(), t["k_codes"].data_ptr(),
+                                           t["v_codes"].data_ptr(), 0, 0, kp.data_ptr(), kp.data_ptr(), t["k_res"].data_ptr(),
+                                           t["v_res"].data_ptr(), t["q"].data_ptr(), ws.data_ptr(), need, 0)
+    assert rc == -2 and "k_new / v_new" in lib.million_last_error().decode()
+    pages = torch.zeros(2 * 11 * 64 * 64 + 16, dtype=torch.uint8, device="cuda")
+    assert lib.million_transpose_v_codes(t["v_codes"].data_ptr(), pages.data_ptr() + 2, 1, 2, 700, 64, 2 * 700 * 64, 700 * 64, 0) == -2
+    assert lib.million_transpose_v_codes(t["v_codes"].data_ptr(), pages.data_ptr(), 1, 2, 700, 64, 2 * 700 * 64 + 4, 700 * 64, 0) == -2
+    assert "16-byte alignment" in lib.million_last_error().decode()
+    rc, msg, out, _ = _raw_attn_call(torch, ops, L, c, M, C)                           # and the library is none the worse for it
+    assert rc == 0, msg
+    _check(out.cpu().numpy(), gold, "good call after the refused ones")
+    assert ops.tail_faults() == 0
+
+
+def test_bindings_10arg_from_two_host_threads(env, oracle):
+    """Re-entrancy ("no globals except a per-device table guarded by a mutex"): the reference's 10-argument call from
+    TWO HOST THREADS at once, each on its own stream (ctypes drops the GIL around the C call, so the two threads are inside
+    libmillion_hip.so together), on two shapes that take two different kernels; a third thread keeps provoking refused calls and
+    reads its own thread-local million_last_error().  Every output against the oracle."""
+    import threading
+    torch, ops = env
+    import bindings
+    from million_amd import _lib as L
+    lib = L.load()
+    specs = [(9911, 1, 32, 8, 128, 64, 256, 6000, 77), (9912, 2, 8, 2, 64, 32, 256, 3000, 30)]
+    cases = [synth.attn_case(s, bs, nh, nhk, d, M, C, T, r, Lt=d) for s, bs, nh, nhk, d, M, C, T, r in specs]
+    golds = [oracle.decode_attn(**c) for c in cases]
+    n_calls, results, errors = 40, [[], []], []
+    start = threading.Barrier(3)
+
+    def worker(i):
+        try:
+            _, bs, nh, nhk, d, M, C, T, r = specs[i]
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                t = _dev(torch, cases[i])
+                fn = getattr(bindings, f"flash_decoding_allocated_buffer_f16u8_Ns16Lt{d}d{d}M{M}C{C}")
+                po = torch.empty(bs, nh, 17, d, dtype=torch.float16, device="cuda")
+                pl = torch.empty(bs, nh, 17, dtype=torch.float16, device="cuda")
+                stream.synchronize()
+                start.wait()
+                for _ in range(n_calls):
+                    results[i].append(fn(t["q"], t["k_codes"], t["v_codes"], t["k_cents"], t["v_cents"], t["k_res"], t["v_res"], r, po, pl))
+                stream.synchronize()
+        except Exception as e:      # noqa: BLE001 - reported by the main thread
+            errors.append((i, repr(e)))
+
+    def refuser():
+        try:
+            start.wait()
+            for k in range(200):
+                assert lib.million_workspace_init(0, 16, 0) == -3
+                assert lib.million_last_error() == b"workspace_init: null"
+                assert lib.million_lengths_advance(0, 1, 64, 128, 0) == -3
+                assert lib.million_last_error() == b"lengths_advance: bad argument"
+        except Exception as e:      # noqa: BLE001
+            errors.append(("refuser", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(0,)), threading.Thread(target=worker, args=(1,)), threading.Thread(target=refuser)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        assert len(results[i]) == n_calls
+        for k, o in enumerate(results[i]):
+            _check(o.cpu().numpy(), golds[i], f"thread {i} call {k}")
+    assert ops.tail_faults() == 0
+
+
+def test_cabi_bench_c_program(env):
+    """tools/cabi_bench.c - the plain-C caller of the ABI (no Python, no torch; the reference's counterpart is the C++ harness
+    Kernel_Test/main.cu:59-226): codebook -> prompt encoded into pages -> decode launches through million_pq_decode_attn_append
+    (graph replay) -> its own host check of codes (bit-exact) and outputs (1e-3).  Built here if the box has no binary yet."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    exe = root / "build" / "cabi_bench"
+    src = root / "tools" / "cabi_bench.c"
+    if not exe.exists() or exe.stat().st_mtime < src.stat().st_mtime:
+        b = subprocess.run(["make", "-C", str(root), "cabi-bench"], capture_output=True, text=True, timeout=600)
+        assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+    for extra in (["--ctx", "4096", "--layers", "4", "--launches", "16"], ["--ctx", "8192", "--M", "32", "--bs", "2", "--layers", "2", "--launches", "8"]):
+        r = subprocess.run([str(exe), *extra, "--reps", "2"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "cabi_bench: PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "0 of" in r.stdout and "kernel kind 1" in r.stdout, r.stdout

@@ -74,9 +74,9 @@ def _worker(rank, world, port, out):
         time.sleep(0.01 * (1 + 2 * rank))       # rank 1 is 3x slower: the job time must be rank 1's
         done.append(1)
 
-    elapsed = sharding.timed_steps(step, 5, lambda: None, dist)
+    elapsed, per_rank = sharding.timed_steps_per_rank(step, 5, lambda: None, dist)
     value, ms = sharding.aggregate_throughput(1, 5, elapsed, world)
-    out.put((rank, len(done), elapsed, value, ms, sharding.shard_requests(5, world, rank)))
+    out.put((rank, len(done), elapsed, value, ms, sharding.shard_requests(5, world, rank), per_rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,8 +94,11 @@ def test_multirank_timing_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, n0, e0, v0, ms0, s0), (r1, n1, e1, v1, ms1, s1) = res
+    (r0, n0, e0, v0, ms0, s0, pr0), (r1, n1, e1, v1, ms1, s1, pr1) = res
     assert n0 == n1 == 5
+    # every rank holds the same list of the ranks' OWN times, indexed by rank: the slow rank is visible (rank 1 sleeps 3x as long)
+    assert pr0 == pr1 and len(pr0) == 2
+    assert pr0[1] >= 5 * 0.03 * 0.9 and pr0[0] < 0.7 * pr0[1] and max(pr0) <= e0
     assert e0 == e1 and e0 >= 5 * 0.03 * 0.9            # both ranks report rank 1's (max) time
     assert v0 == v1 == pytest.approx(10 / e0)
     assert s0 + s1 == list(range(5))
@@ -120,6 +123,10 @@ def test_bench_launcher_spawns_ranks_dry_cpu():
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["scaling"] == "weak"
     assert [x[0] for x in rec["config"]["ranks_seen"]] == [0, 1]
     assert rec["config"]["batch_per_gpu"] == 2
+    # a slow rank is visible in the line: each rank's own ms per step and launch period / roofline fraction, indexed by rank
+    pr = rec["per_rank_ms_per_step"]
+    assert len(pr) == 2 and pr[1] > 1.5 * pr[0] and max(pr) <= rec["ms_per_step"] * 1.001
+    assert len(rec["roofline"]["per_rank"]["frac"]) == 2 and len(rec["roofline"]["per_rank"]["launch_us_mean"]) == 2
     # rank 1's step sleeps twice as long: the job time is rank 1's, the value counts both ranks' requests
     assert rec["ms_per_step"] >= 4.0 * 0.9 and rec["value"] == pytest.approx(2 * 2 * 1000.0 / rec["ms_per_step"], rel=1e-3)
 
