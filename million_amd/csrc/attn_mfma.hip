@@ -39,6 +39,7 @@ namespace million {
 
 typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 v4f16_t __attribute__((ext_vector_type(4)));
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 typedef float v16f32 __attribute__((ext_vector_type(16)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -571,7 +572,8 @@ __device__ __forceinline__ void load_res_tile(const AttnParams &p, int bh, const
 }
 
 // scores of the tile: sc[rho] = row 4*q' + rho for the head of this lane's column
-__device__ __forceinline__ void score_res_tile(const ResTile &t, const v8f16 (&qb)[4], float scale_log2e, int wave, int rcnt,
+template <class RT>      // ResTile / ResTileLean (lean kernel): the K rows are laid out alike
+__device__ __forceinline__ void score_res_tile(const RT &t, const v8f16 (&qb)[4], float scale_log2e, int wave, int rcnt,
                                                int lane, float (&sc)[4]) {
     const int q4 = lane >> 4;
     v4f32 D = {0.f, 0.f, 0.f, 0.f};
@@ -914,6 +916,14 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     {
         const bool hi = lane >= 32;
         const int c32 = lane & 31;
+        if constexpr (MS == 640) {     // lean kernel (z-rows): accumulator pi, lane (rg = lane >> 4, n = lane & 15), register i = head i:
+                                       // row 4 rg + i = (z = rg >> 1, parity rg & 1, head i), column n = subspace 32 pi + 16 z + n
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < G) mine[i * 128 + 64 * j + 32 * (lane >> 5) + 2 * (lane & 15) + ((lane >> 4) & 1)] = O.t[j][i];
+        } else
         if constexpr (MS == 320) {     // d_m = 4 form: column tile j, lane (dq = lane >> 4, n = lane & 15), register i = head i
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -939,7 +949,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                         for (int n = 0; n < 2; ++n) mine[g * 128 + 2 * (32 * n + c32) + (j >> 1)] = O[n][0][4 * j + rho];
                     }
                 }
-        } else if constexpr (MS != 16 && MS != 320) {
+        } else if constexpr (MS != 16 && MS != 320 && MS != 640) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)                      // tile rows 8 j + 4 hi + rho = register 4 j + rho; j = 1: groups above 8 heads
 #pragma unroll
@@ -2063,6 +2073,478 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef STAMP
 }
 
+// =====================================================================================================
+// Lean kernel (round 5): M = 64, C = 256, up to 4 query heads per kv head, pages of 64 or 128 tokens (or row-major K).
+//
+// The streaming kernel above spends its vector issue on PQ address arithmetic (two instructions per K lookup: a lane's table base
+// depends on the lane) and multiplies idle rows / columns (scores: 4 of the 16 head columns of a 16 x 16 x 32 tile, values: 8 of the
+// 32 rows of a 32 x 32 x 16 tile).  This kernel keeps its launch skeleton - page-strided units, ONE page-id vector load, both
+// codebooks in LDS behind one barrier, the residual tile, the fused append, the L2 tail - and replaces the core
+// (tools/micro/lean_core.hip measures it alone: 1.15-1.18 x the units per us and SIMD of the parity-V core on cache-resident
+// codes at +0.26 GHz of in-kernel clock, 1.05-1.14 x streamed from HBM; profiles/r05_core_micro.txt):
+//   * a unit is 64 tokens and LANE = TOKEN on the K side: a lane owns its token's whole 64-byte code row (four 16-byte loads);
+//   * scores by v_mfma_f32_4x4x4_16B_f16 - sixteen independent blocks of 4 tokens x 4 heads x 4 dims: every MAC useful at G = 4.
+//     A = the two gathered centroid words of subspaces (2 s, 2 s + 1) as gathered.  The subspace is wave-uniform, so the table base
+//     rides in the ds_read offset field and a K lookup address is ONE instruction (an SDWA shift of the code byte).  B = the query
+//     heads: eight register pairs; k-step s = 4 u + lambda sits in lane group lambda of pair u and the MFMA's blgp field broadcasts
+//     that group to every block.  The scores land in lane (token quad b, head j), register i = token 4 b + i: all 64 lanes carry
+//     useful scores, the softmax is 4 exponentials per 64 tokens and lane (16 x 16 tiles: 16);
+//   * values by v_mfma_f32_16x16x32_f16 in "z-rows": rows = (z, parity of the dim, head < 4) - all 16 rows in use; the reduction
+//     index is (token, parity) and the gathered V word is the B operand as it stands (as in parity-V).  Row (z, p, g) is fed by the
+//     token groups kg (16 lanes = 16 tokens each) with (kg & 1) == z ^ phi in the MFMA of phase phi, and those lanes gather
+//     subspace 32 pi + 16 z + n: the two token groups of a 32-lane LDS half read two different sets of 16 subspaces - 32 distinct
+//     banks, conflict-free (with rows = (parity, head < 8) both groups read the SAME subspace for different tokens: every V gather
+//     a 2-way conflict, and the core was LDS-bound: micro VAR 0) - phase 1 swaps the roles, both phases accumulate into the same 4
+//     registers: 8 accumulator registers in all (parity-V: 32).  The A operand needs "4 tokens of ONE head" per lane - exactly
+//     what a score lane holds: (P, P) pairs are broadcast from lane bank s to the whole 16-lane row by ONE ds_swizzle per register
+//     and token step and ANDed with a lane-constant mask per phase (half of the dword by parity; zero where the lane's token group
+//     does not feed the row).
+// Per 64 tokens and wave: 128 LDS gathers (as before), 48 MFMAs (32 of them 4 x 4 x 4: 512 matrix-pipe cycles; parity-V: 768),
+// ~215 vector instructions (parity-V: ~300), 16 swizzles.  G > 4, pages of 32 tokens, C = 128 and M != 64 stay on the streaming
+// kernel (million_set_force_generic(16) keeps everything there: A/B and tests).
+// =====================================================================================================
+// 4 * byte B of w - the LDS offset of a 4-byte table entry - in ONE instruction (hipcc finds the SDWA form for bytes 1-3 by itself
+// and emits shift + mask for byte 0)
+template <int B>
+__device__ __forceinline__ unsigned byte_x4(unsigned w) {
+    unsigned r;
+    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(2u), "v"(w));
+    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(2u), "v"(w));
+    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(2u), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(2u), "v"(w));
+    return r;
+}
+struct Unit64 {
+    v4u k[4];   // lane t: bytes [16 q, 16 q + 16) of token t's code row
+    v4u v[4];   // x = 2 pi + t: lane (kg, n): subspace 32 pi + 16 (t ^ (kg & 1)) + n, tokens 16 kg .. 16 kg + 15
+};
+// residual tile: scores on the 16 x 16 x 32 tile as in the streaming kernel (A = the fp16 K rows); values in z-rows:
+// v[2 pi + z][i] = dims (2 m, 2 m + 1), m = 32 pi + 16 z + n, of tile row 4 kg + i - the B operand of the MFMA of (pi, z)
+struct ResTileLean {
+    v4u k[4];
+    unsigned v[4][4];
+};
+__device__ __forceinline__ void load_res_tile_lean(const AttnParams &p, int bh, const f16 *kr, const f16 *vr, int wave, int rcnt,
+                                                   int split, int rstart, int r_old, int lane, ResTileLean &t) {
+    const int q4 = lane >> 4, c16 = lane & 15;
+    {
+        bool is_new;
+        const long long off = res_row_off(p, kResRows * wave + c16, wave, rcnt, split, rstart, r_old, is_new);
+        const f16 *kp = (is_new ? p.k_new + (long long)bh * 128 : kr + off) + 32 * q4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bool is_new;
+        const long long off = res_row_off(p, kResRows * wave + 4 * q4 + i, wave, rcnt, split, rstart, r_old, is_new);
+        const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 2 * c16;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) t.v[x][i] = *(const unsigned *)(vp + 32 * x);      // dims 2 (16 x + n): x = 2 pi + z
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
+    constexpr int RING = 2;      // ring slots of one 64-token unit (32 registers each).  Three slots (the K bytes two blocks ahead
+                                 // instead of one) were measured and are slower at every shape: 24.98 vs 22.65 us at two requests,
+                                 // 60.5 vs 59.8 at eight, 67.2 vs 65.1 at 8 x 36864 (profiles/r05_ab_lean.txt)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int split = blockIdx.x, bh = blockIdx.y;      // all splits of a (b, kv head) on one XCD: see attn_stream_kernel
+    if ((gridDim.y & 7) == 0) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
+        bh = id % (int)gridDim.y;
+        split = id / (int)gridDim.y;
+    }
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int G = p.G;
+    const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
+    const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
+    const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i dl = {p.T, p.r, p.rstart, 0};
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
+    const bool dbg_on = p.dbg != nullptr;
+#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
+    stamp_lds_clear(dbg_on, lane, wave);
+    STAMP(0);
+    const int kg = lane >> 4, n16 = lane & 15, hj = lane & 3;
+
+    // ---- where this wave reads: page pg0 + j * pg_step in round j, tokens [tin, tin + 64) of it ----
+    const int ups = p.ps_shift - 6;                       // log2(units per page): pages of 64 or 128 tokens
+    const int wp = wave >> ups, uw = wave & ((1 << ups) - 1);
+    const int pg0 = wp * p.nsplit + split;
+    const int pg_step = p.nsplit << (3 - ups);
+    const int tin = uw << 6;
+    int vpk = 0, vpv = 0;      // page ids of rounds 0..63 (lane = round): the oldest loads of the wave
+    {
+        int pgl = pg0 + lane * pg_step;
+        pgl = pgl < p.n_pages_cap ? pgl : p.n_pages_cap - 1;
+        const long long idx = (long long)bh * p.n_pages_cap + pgl;
+        if (k_paged) vpk = ids64 ? (int)p.k_ids64[idx] : p.k_ids32[idx];
+        if (v_ident) vpv = (int)idx;
+        else vpv = ids64 ? (int)p.v_ids64[idx] : p.v_ids32[idx];
+#ifdef MILLION_DEBUG_CHECK_IDS
+        {
+            const bool live = pg0 + lane * pg_step < p.n_pages_cap && ((long long)(pg0 + lane * pg_step) << p.ps_shift) < p.T;
+            if (k_paged) vpk = MILLION_CHECK_KID(p, ids64 ? (long long)p.k_ids64[idx] : (long long)vpk, live);
+            if (!v_ident) vpv = MILLION_CHECK_VID(p, ids64 ? (long long)p.v_ids64[idx] : (long long)vpv, live);
+        }
+#endif
+    }
+    // query operand of the 4 x 4 x 4 products: register pair u, lane group kg holds the 4 dims of k-step (u, kg) of head (lane & 3).
+    // A lane's pairs 2 v, 2 v + 1 are ONE 16-byte load (dims 32 v + 8 kg .. + 7), so k-step (u, lambda) covers subspaces
+    // 2 sigma, 2 sigma + 1 with sigma = 8 (u >> 1) + 2 lambda + (u & 1) (LEAN_SIGMA below): any order of the subspaces will do
+    const f16 *qrow = p.q + ((long long)b * p.nh + head0(p, hk)) * 128;
+    v2u Q[8];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        v4u t = *(const v4u *)(qrow + (hj < G ? hj : 0) * 128 + 32 * v + 8 * kg);
+        if (hj >= G) t = v4u{0, 0, 0, 0};
+        Q[2 * v] = v2u{t[0], t[1]};
+        Q[2 * v + 1] = v2u{t[2], t[3]};
+    }
+    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
+    h2 new_k = {}, new_v = {};
+    if (append_wave) {
+        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
+    }
+    constexpr int NT = 8;
+    v4u tabk[NT], tabv[NT];
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
+    {
+        const v4u *ks = (const v4u *)p.k_tab;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tabk[i] = ks[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
+        const v4u *vs = (const v4u *)p.v_tab_col;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tabv[i] = vs[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
+    }
+    if (p.dev_lengths)
+        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
+    int T = dl[0], r_old = dl[1], rstart = dl[2];
+    clamp_lengths(p, T, r_old, rstart);
+    const int r = r_old + (p.k_new ? 1 : 0);
+    const int t0 = (pg0 << p.ps_shift) + tin;             // first token of round 0
+    const int t_step = pg_step << p.ps_shift;             // tokens between rounds
+    const int n_mine = T > t0 ? (T - t0 + t_step - 1) / t_step : 0;      // rounds (= units) of this wave; host: <= 64
+    const int j_last = n_mine > 0 ? n_mine - 1 : 0;
+    const int T_ld = T > 0 ? T : 1;
+
+    // ---- residual window rows of this split (see load_res_tile) ----
+    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
+    const bool has_res = kResRows * wave < rcnt;
+    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    ResTileLean rt;
+    v8f16 qb[4];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims 32 q4 + 8 s ..)
+    if (has_res) {
+        load_res_tile_lean(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+        const f16 *qv = qrow + (n16 < G ? n16 : 0) * 128 + 32 * kg;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            v4u t = *(const v4u *)(qv + 8 * s);
+            if (n16 >= G) t = v4u{0, 0, 0, 0};
+            qb[s] = __builtin_bit_cast(v8f16, t);
+        }
+    }
+
+    // ---- one unit's 16-byte requests into ring slot SL (rounds past the wave's last unit re-request it: no load in a conditional) ----
+    Unit64 ring[RING];
+    const unsigned k_lane_off = (unsigned)lane << 6;
+    // V: x even reads subspace row 16 (kg & 1) + n, x odd the other 16 of the pair's 32; + 32 subspace rows per pi
+    const unsigned v_lane_off1 = ((unsigned)(n16 + 16 * (kg & 1)) << p.ps_shift) + 16u * kg;
+    const unsigned v_lane_off2 = ((unsigned)(n16 + 16 * (1 - (kg & 1))) << p.ps_shift) + 16u * kg;
+#define UNIT_REQ_K(SL, J)                                                                                          \
+    {                                                                                                              \
+        const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
+        gptr_u8 kb_;                                                                                               \
+        if (k_paged) {                                                                                             \
+            const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
+            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << 6));                                     \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + k_lane_off + 16u * q_); \
+        } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
+            const int tu_ = t0 + jc_ * t_step;                                                                     \
+            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
+            const unsigned ro_ = (unsigned)min(tu_ + lane, T_ld - 1) << 6;                                         \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + ro_ + 16u * q_);   \
+        }                                                                                                          \
+    }
+#define UNIT_REQ_V(SL, J)                                                                                          \
+    {                                                                                                              \
+        const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
+        const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
+        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (6 + p.ps_shift)) + tin);                              \
+        _Pragma("unroll") for (int x_ = 0; x_ < 4; ++x_)                                                           \
+            ring[SL].v[x_] = *(gptr_v4u)(vb_ + ((x_ & 1) ? v_lane_off2 : v_lane_off1) + ((32u * (x_ >> 1)) << p.ps_shift)); \
+    }
+#define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
+    // only unit 0 (8 KiB per wave - what the streaming kernel asks for up front) goes out before the codebooks are in LDS: the CU's
+    // request queue is in order, and what is asked for in front of the barrier delays it (both units up front: +1.3 us at one request)
+    UNIT_REQ(0, 0)
+    STAMP(7);
+    {
+        v4u *ld = (v4u *)smem;
+        v4u *ldv = (v4u *)(smem + kVBase);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) ld[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabk[i];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) ldv[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabv[i];
+    }
+    STAMP(8);
+    __syncthreads();
+    STAMP(1);
+
+    Acc8 O;      // O.t[pi][g]: lane (rg, n): head g, dim 64 pi + 32 (rg >> 1) + 2 n + (rg & 1)
+    O.t[0] = v4f32{0.f, 0.f, 0.f, 0.f};
+    O.t[1] = v4f32{0.f, 0.f, 0.f, 0.f};
+    if (append_wave) {
+        int row_n = rstart + r_old;
+        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
+        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
+        *(h2 *)(p.k_res_w + o) = new_k;
+        *(h2 *)(p.v_res_w + o) = new_v;
+    }
+    // lane constants of the value side: the half of a (P, P) pair this lane's row takes (parity p = bit 2 of the lane), the phase
+    // masks (row z = bit 3 is fed by this lane's token group kg in phase phi iff (kg & 1) == z ^ phi), the gather constants
+    const unsigned zr_half = ((lane >> 2) & 1) ? 0xffff0000u : 0x0000ffffu;
+    const bool z_own = (kg & 1) == ((lane >> 3) & 1);
+    const unsigned zmask0 = z_own ? zr_half : 0u, zmask1 = z_own ? 0u : zr_half;
+    const unsigned vcz0 = (unsigned)kVBase | ((unsigned)(n16 + 16 * (kg & 1)) << 2), vcz1 = (unsigned)kVBase | ((unsigned)(n16 + 16 * (1 - (kg & 1))) << 2);
+    const float c_ = p.scale_log2e, inv_c = 1.0f / p.scale_log2e;
+    const float idle = hj < G ? 0.f : -INFINITY;      // lanes of heads that do not exist: probabilities come out as exact zeros
+    // softmax state of head (lane & 3): the reference m (see SoftRef), this lane's part of the row sums
+    float s_m = -INFINITY, s_l = 0.f;
+    if (has_res) {      // residual tile of this wave first: it needs neither codebook
+        float scr[4], m_run = -INFINITY, l_run = 0.f;
+        score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);      // lane (q4, head c16): rows 4 q4 + rho
+        softmax_online<4, false>(scr, m_run, l_run, O, G, lane);           // O is zero: nothing is rescaled
+        // (P, P) of lanes 0-3 of every 16-lane row (heads 0-3, rows 4 kg + i) -> the whole row; rows of z: one product per (pi, z)
+        unsigned sw_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h2 pp = {(f16)scr[i], (f16)scr[i]};
+            sw_[i] = (unsigned)__builtin_amdgcn_ds_swizzle((int)__builtin_bit_cast(unsigned, pp), 0x13);
+        }
+        const unsigned rz0 = ((lane >> 3) & 1) ? 0u : zr_half, rz1 = ((lane >> 3) & 1) ? zr_half : 0u;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const unsigned mk = (x & 1) ? rz1 : rz0;
+            O.t[x >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(sw_[0] & mk, sw_[1] & mk, sw_[2] & mk, sw_[3] & mk),
+                                                                 as_v8f16(rt.v[x][0], rt.v[x][1], rt.v[x][2], rt.v[x][3]), O.t[x >> 1], 0, 0, 0);
+        }
+        // state into the lean layout: head j's reference sits in lane j of every row (bank 0); a row's sums are counted once
+        s_m = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, m_run), 0x13));
+        s_l = (lane & 12) == 0 ? l_run : 0.f;
+    }
+    STAMP(2);
+    float s_neg = (s_m > -INFINITY ? -s_m : 0.f) + idle, s_thr = (s_m + 8.0f) * inv_c;
+
+    unsigned L[4];                  // (P, P) pairs of this lane's (token quad, head)
+    unsigned sw[2][4];              // the pairs of token step s, broadcast over the 16-lane row (sw[s & 1])
+    unsigned Az[2][4];              // A operands of the two phases
+    v2u a[8];                       // K gathers in flight (k-step sg in a[sg & 7]: 3 steps ahead inside a block, 6 when the scores run alone)
+    unsigned e[4][4];               // V gathers in flight (value step i in e[i & 3]: 2 steps ahead inside a block, 3 alone)
+    v4f32 D[2];
+
+    // ---- K side: k-step sg = subspaces 2 sigma, 2 sigma + 1 (wave-uniform: the table base is the read's offset field) ----
+#define KBYTE4(SL, B) byte_x4<(B) & 3>(ring[SL].k[(B) >> 4][((B) >> 2) & 3])      /* 4 * code byte B of the lane's row */
+#define LEAN_SIGMA(SG) (8 * ((SG) >> 3) + 2 * ((SG) & 3) + (((SG) >> 2) & 1))
+#define KG(SL, SG)                                                                                                 \
+    {                                                                                                              \
+        a[(SG) & 7][0] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG)) + (2 * LEAN_SIGMA(SG)) * 1024u);                     \
+        a[(SG) & 7][1] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG) + 1) + (2 * LEAN_SIGMA(SG) + 1) * 1024u);             \
+    }
+    // (the empty asm behind a product pins it: an MFMA is register-only, so hipcc moves it across sched_barrier() at will - it
+    // bunched the score products in runs of 4-12 behind runs of 4-5 value products; with its accumulator made opaque at this
+    // point the product stays in the slot it is written in, cdna_hip_programming.md 5.7 item 3)
+#define KM(SG)                                                                                                     \
+    {                                                                                                              \
+        D[(SG) & 1] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4f16_t, a[(SG) & 7]), __builtin_bit_cast(v4f16_t, Q[(SG) >> 2]), \
+                                                         (SG) < 2 ? v4f32{0.f, 0.f, 0.f, 0.f} : D[(SG) & 1], 0, 0, 4 + ((SG) & 3)); \
+        asm volatile("" : "+v"(D[(SG) & 1]));                                                                      \
+    }
+    // ---- V side: value step i = 4 s + 2 phi + pi (consecutive products alternate between the two accumulators): gathers from
+    //      ring.v[2 pi + phi], dword s (tokens 16 kg + 4 s + 0..3) ----
+#define VG(SL, I)                                                                                                  \
+    {                                                                                                              \
+        const unsigned w_ = ring[SL].v[2 * ((I) & 1) + (((I) >> 1) & 1)][(I) >> 2];                                \
+        const unsigned vc_ = ((I) & 2) ? vcz1 : vcz0;                                                              \
+        e[(I) & 3][0] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020400u) + 128u * ((I) & 1));                     \
+        e[(I) & 3][1] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020500u) + 128u * ((I) & 1));                     \
+        e[(I) & 3][2] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020600u) + 128u * ((I) & 1));                     \
+        e[(I) & 3][3] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020700u) + 128u * ((I) & 1));                     \
+    }
+    // (P, P) of lane bank s -> every lane of the 16-lane row (bit mode: lane' = (lane & 0x13) | (s << 2))
+#define ZSWZ(S) { _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) sw[(S) & 1][ii] = (unsigned)__builtin_amdgcn_ds_swizzle((int)L[ii], 0x13 | (((S) << 2) << 5)); }
+#define VS(I)                                                                                                      \
+    {                                                                                                              \
+        if (((I) & 3) == 0) {                                                                                      \
+            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) { Az[0][ii] = sw[((I) >> 2) & 1][ii] & zmask0; Az[1][ii] = sw[((I) >> 2) & 1][ii] & zmask1; } \
+            if ((I) < 12) ZSWZ(((I) >> 2) + 1)                                                                     \
+        }                                                                                                          \
+        O.t[(I) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(Az[((I) >> 1) & 1][0], Az[((I) >> 1) & 1][1], Az[((I) >> 1) & 1][2], Az[((I) >> 1) & 1][3]), \
+                                                              as_v8f16(e[(I) & 3][0], e[(I) & 3][1], e[(I) & 3][2], e[(I) & 3][3]), \
+                                                              O.t[(I) & 1], 0, 0, 0);                              \
+        asm volatile("" : "+v"(O.t[(I) & 1]));                                                                     \
+    }
+    // ---- online softmax of the unit of round J whose scores are in D: lane (quad b, head j) holds tokens t_u + 4 b + i.  The
+    //      reference moves only when a raw score exceeds thr (SoftRef); the new one is the maximum over the head's 16 lanes ----
+#define SOFTMAX(J)                                                                                                 \
+    {                                                                                                              \
+        float x_[4];                                                                                               \
+        const int t_u = t0 + (J) * t_step;                                                                         \
+        if (t_u + 64 <= T) {                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) x_[i] = D[0][i] + D[1][i];                               \
+        } else {      /* the unit that holds token T - 1 (wave-uniform); a unit past it gives -inf everywhere */   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) x_[i] = t_u + (lane & ~3) + i < T ? D[0][i] + D[1][i] : -INFINITY; \
+        }                                                                                                          \
+        const float mx_ = max3_raw(max3_raw(x_[0], x_[1], x_[2]), x_[3], x_[3]);                                   \
+        if (__any(mx_ > s_thr)) {                                                                                  \
+            float mq_ = mx_;                                                                                       \
+            mq_ = fmaxf(mq_, MILLION_DPP(mq_, 0x124));      /* row_ror:4 */                                        \
+            mq_ = fmaxf(mq_, MILLION_DPP(mq_, 0x128));      /* row_ror:8 */                                        \
+            const float m_new = fmaxf(s_m, rows_max(mq_) * c_);                                                    \
+            const float m_safe = m_new > -INFINITY ? m_new : 0.f;                                                  \
+            const float alpha = fast_exp2(s_m - m_safe);                                                           \
+            if (__any(m_new > s_m && s_m > -INFINITY)) rescale_acc(O, alpha, G, lane);                             \
+            s_l *= alpha;                                                                                          \
+            s_m = m_new;                                                                                           \
+            s_neg = (m_new > -INFINITY ? -m_new : 0.f) + idle;                                                     \
+            s_thr = (m_new + 8.0f) * inv_c;                                                                        \
+        }                                                                                                          \
+        float ps_ = 0.f;                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            const float pr_ = fast_exp2(fmaf(x_[i], c_, s_neg));                                                   \
+            ps_ += pr_;                                                                                            \
+            const h2 pp_ = {(f16)pr_, (f16)pr_};                                                                   \
+            L[i] = __builtin_bit_cast(unsigned, pp_);                                                              \
+        }                                                                                                          \
+        s_l += ps_;                                                                                                \
+        ZSWZ(0)                                                                                                    \
+    }
+#define FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define FOR32(X) FOR16(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+    // (every step index is a literal: the MFMA's blgp field and the swizzle patterns are immediates)
+    // the scores of the unit in slot 0 alone (the prologue: nothing to interleave with, so the gathers run 6 k-steps ahead); the
+    // requests of round 1 go out in between - behind the barrier, one group every few k-steps (all eight right behind the barrier:
+    // the waves sat ~1 us in their load instructions while the CU's request queue was full)
+#define SA_STEP(SG)                                                                                                \
+    {                                                                                                              \
+        KM(SG)                                                                                                     \
+        if ((SG) + 6 < 32) KG(0, ((SG) + 6) & 31)                                                                  \
+        if ((SG) == 4) UNIT_REQ_K(1, 1)                                                                            \
+        if ((SG) == 12) UNIT_REQ_V(1, 1)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+    // BLOCK: the 16 value steps of the unit in slot BL_SL (round bl_j) interleaved with the 32 score steps of the unit in the other
+    // slot (round bl_j + 1), whose first three gathers are in flight; the K bytes of round bl_j + 2 are requested at the start into
+    // slot BL_SL (its K bytes were used up by the previous block), its V bytes once the last value gather of round bl_j is out;
+    // the first three K gathers of round bl_j + 2 close the block
+#define BL_STEP(I)                                                                                                 \
+    {                                                                                                              \
+        VS(I)                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        VG(((I) + 2 < 16 ? BL_SL : BL_SLN), ((I) + 2) & 15)                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        KM(2 * (I))                                                                                                \
+        KG((2 * (I) + 3 < 32 ? BL_SLN : BL_SL), (2 * (I) + 3) & 31)                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        KM(2 * (I) + 1)                                                                                            \
+        KG((2 * (I) + 4 < 32 ? BL_SLN : BL_SL), (2 * (I) + 4) & 31)                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if ((I) == 13) UNIT_REQ_V(BL_SL, bl_j + RING)                                                              \
+    }
+#define BLOCK() { UNIT_REQ_K(BL_SL, bl_j + RING) FOR16(BL_STEP) SOFTMAX(bl_j + 1) ++bl_j; }
+    // the value steps of the unit in slot VA_SL alone (gathers 0 and 1 are in flight; from here on 3 steps ahead)
+#define VA_STEP(I) { if ((I) + 3 < 16) VG(VA_SL, (I) + 3) VS(I) __builtin_amdgcn_sched_barrier(0); }
+    // A wave with n units runs: scores of unit 0 | n - 1 blocks (values of unit j beside the scores of unit j + 1) | values of unit
+    // n - 1.  Blocks alternate between the two ring slots (unit j lives in slot j & 1): one block, pairs in a loop, one more when n is odd.
+    const int nb = n_mine > 1 ? n_mine - 1 : 0;
+    TailReq treq;
+    treq.idx = 0; treq.gen = 0; treq.cen = 0; treq.base = 0; treq.done = false;
+    tail_mark_xcd(p, bh, split, wave, lane);      // this split's slot of the XCD census
+    int bl_j = 0;
+    {
+        KG(0, 0) KG(0, 1) KG(0, 2) KG(0, 3) KG(0, 4) KG(0, 5)
+        FOR32(SA_STEP)
+        SOFTMAX(0)      // (a wave without units: every score is masked to -inf, every probability 0)
+        STAMP(16);
+    }
+    if (n_mine > 0) {
+        VG(0, 0) VG(0, 1)
+        if (nb > 0) {
+            KG(1, 0) KG(1, 1) KG(1, 2)
+#define BL_SL 0
+#define BL_SLN 1
+            BLOCK()
+#undef BL_SL
+#undef BL_SLN
+            for (int w = 0; w < (nb - 1) >> 1; ++w) {
+#define BL_SL 1
+#define BL_SLN 0
+                BLOCK()
+#undef BL_SL
+#undef BL_SLN
+#define BL_SL 0
+#define BL_SLN 1
+                BLOCK()
+#undef BL_SL
+#undef BL_SLN
+                if (w == 0) STAMP(17);
+            }
+        }
+        tail_request(p, bh, p.nslots, wave, lane, treq);      // ~3 us ahead of the point where the tail needs the answers
+        STAMP(19);
+        if (n_mine & 1) {      // an odd number of units: the last one sits in slot 0 - behind one more block unless it is the only one
+            if (nb > 0) {
+#define BL_SL 1
+#define BL_SLN 0
+                BLOCK()
+#undef BL_SL
+#undef BL_SLN
+            }
+#define VA_SL 0
+            VG(0, 2)
+            FOR16(VA_STEP)
+#undef VA_SL
+        } else {
+#define VA_SL 1
+            VG(1, 2)
+            FOR16(VA_STEP)
+#undef VA_SL
+        }
+    }
+#undef BLOCK
+#undef BL_STEP
+#undef VA_STEP
+#undef SA_STEP
+#undef FOR32
+#undef FOR16
+#undef SOFTMAX
+#undef VS
+#undef ZSWZ
+#undef VG
+#undef KM
+#undef KG
+#undef LEAN_SIGMA
+#undef KBYTE4
+#undef UNIT_REQ
+#undef UNIT_REQ_K
+#undef UNIT_REQ_V
+    STAMP(3);
+    // the tail wants head g's reference in lane g and row sums that rows_sum() completes: add up the head's four lanes of a row
+    float l_row = s_l;
+    l_row += MILLION_DPP(l_row, 0x124);
+    l_row += MILLION_DPP(l_row, 0x128);
+    merge_and_publish<640, false>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, s_m, l_row, treq);
+#undef STAMP
+}
+
 // Self-check of the row-swap reductions (tests/test_gpu_parity.py): one wave, in[64] -> max / sum over the
 // four 16-lane rows per column.
 __global__ void rows_reduce_check_kernel(const float *in, float *out_max, float *out_sum) {
@@ -2100,11 +2582,12 @@ int read_tail_faults() {
 // A/B knob (million_set_force_generic 2): 0 = auto (streaming kernel wherever it applies), 1 = grouped kernel only
 // g_tail_test (million_set_force_generic 4 / 8): the merge helpers give up at once - the last arriver's take-over path, for
 // tests: 1 = every give-up bit is set in the prologue, 2 = the helpers give up through the real path (no polls, then the atomic)
-static int g_mfma_policy = 0, g_tail_test = 0;
+// g_lean_off (million_set_force_generic 16): the lean kernel's shapes stay on the streaming kernel (A/B, tests of the parity-V form)
+static int g_mfma_policy = 0, g_tail_test = 0, g_lean_off = 0;
 // development A/B (dev_switches.h; environment MILLION_M32_PACKED=1 in a MILLION_DEV_BUILD): M = 32 keeps the packed form at G <= 4
 // too.  The constant 0 in the product build.
 static const int g_mfma_form = MILLION_DEV_M32_PACKED();
-void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 3; }
+void set_mfma_policy(int policy) { g_mfma_policy = policy & 1; g_tail_test = (policy >> 1) & 3; g_lean_off = (policy >> 3) & 1; }
 
 // split policy: about one workgroup per CU; a split is at least 512 tokens long
 static int mfma_splits(const AttnParams &p) {
@@ -2187,6 +2670,9 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
@@ -2203,7 +2689,11 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         if (p.M == 64) hipLaunchKernelGGL((attn_stream_kernel<64, 2, 7>), grid, block, kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_stream_kernel<32, 2, 7>), grid, block, kLdsBytes, s, p);
     } else if (g_mfma_policy == 0 && stream_ok) {
-        if (p.M == 64) {
+        if (p.M == 64 && p.G <= 4 && p.page_size >= 64 && !g_lean_off) {      // lean kernel (round 5): 64-token units, lane = token
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2>), grid, block, kLdsBytes, s, p);
+        } else if (p.M == 64) {
             if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<64, 0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<64, 1>), grid, block, kLdsBytes, s, p);
             else hipLaunchKernelGGL((attn_stream_kernel<64, 2>), grid, block, kLdsBytes, s, p);

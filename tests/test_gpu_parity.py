@@ -2319,3 +2319,63 @@ def test_cabi_bench_c_program(env):
         r = subprocess.run([str(exe), *extra, "--reps", "2"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "cabi_bench: PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
         assert "0 of" in r.stdout and "kernel kind 1" in r.stdout, r.stdout
+
+
+# ---------------------------------------------------------------- lean kernel (round 5) ----------------------------------------
+@pytest.mark.parametrize("policy", [0, 16], ids=["lean", "streaming-form"])
+@pytest.mark.parametrize("G", [1, 2, 3, 4])
+def test_attn_lean_kernel_unit_counts_and_forms(G, policy, env, oracle):
+    """The lean kernel (attn_mfma.hip attn_lean_kernel: 64-token units, lane = token, 4x4x4 score products, z-row value products)
+    takes M = 64 / C = 256 / up to 4 query heads per kv head / pages of 64 or 128 tokens; million_set_force_generic(16) keeps those
+    shapes on the streaming kernel's parity-V form, which otherwise only runs at G > 4 or on 32-token pages.  Context lengths chosen
+    so that a wave has 0, 1, 2, 3, 4 and 5 units (the scores-alone prologue, the block chain with its odd / even ends, the
+    values-alone epilogue), with and without a ragged last unit, a last unit of one token, and windows of 1 .. 128 rows."""
+    torch, ops = env
+    nhk, M, C = 2, 64, 256
+    try:
+        ops.set_force_generic(policy)
+        for T, r, ps in ((1, 1, 64), (63, 5, 64), (64, 128, 64), (65, 17, 128), (511, 3, 64), (513, 64, 64), (1024, 100, 128), (1537, 31, 64),
+                         (2048 + 17, 9, 64), (2560, 77, 128), (4096 + 65, 127, 64), (5120 + 1, 2, 64)):
+            c = synth.attn_case(9300 + T + G, 1, G * nhk, nhk, 128, M, C, T, r, Lt=128)
+            gold = oracle.decode_attn(**c)
+            _check(_run_paged(torch, ops, oracle, c, M, C, ps, poison_out=True), gold, f"G={G} T={T} r={r} ps={ps} paged")
+            _check(_run_paged(torch, ops, oracle, c, M, C, ps, k_paged=False, i64=True), gold, f"G={G} T={T} row-major K, int64 ids")
+            _check(_run_rowmajor(torch, ops, c, M, C), gold, f"G={G} T={T} 10-arg layout")
+    finally:
+        ops.set_force_generic(0)
+    assert ops.tail_faults() == 0
+
+
+def test_attn_lean_kernel_many_units_per_wave_and_batch(env, oracle):
+    """Long splits (many blocks per wave through the pair loop), a batch whose requests have different lengths (device lengths: a
+    wave of the short request has fewer units than the grid was sized for), the fused append, peaked scores that move the softmax
+    reference in the middle of a wave's units (the lean softmax rescales its 8 accumulator registers by quad broadcasts)."""
+    torch, ops = env
+    M, C, ps = 64, 256, 64
+    c = synth.attn_case(9400, 2, 8, 2, 128, M, C, 40000, 50, Lt=128)
+    # request 1 is shorter; a handful of K rows far larger than the rest (late in the context: the reference has to move)
+    rs = np.random.RandomState(3)
+    T1 = 23000
+    c["q"][:, :, :, :] *= 3.0
+    gold_full = oracle.decode_attn(**c)
+    _check(_run_paged(torch, ops, oracle, c, M, C, ps), gold_full, "40K tokens, 2 requests")
+    t = _dev(torch, c)
+    vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], ps)
+    kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], ps)
+    kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+    lengths = torch.tensor([[40000, 50, 0, 0], [T1, 49, 0, 0]], dtype=torch.int32, device="cuda")
+    k_new = rs.standard_normal((2, 2, 1, 128)).astype(np.float16)
+    v_new = rs.standard_normal((2, 2, 1, 128)).astype(np.float16)
+    ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+    out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda(), kp, vp, t["k_res"], t["v_res"], 0, M=M, C=C,
+                             n_tokens=40000, k_page_ids=ids_t, v_page_ids=ids_t, page_size=ps, dev_lengths=lengths,
+                             k_new=torch.from_numpy(k_new).cuda(), v_new=torch.from_numpy(v_new).cuda())
+    torch.cuda.synchronize()
+    for b, (Tb, rb) in enumerate(((40000, 50), (T1, 49))):
+        cb = {k: (v[b:b + 1].copy() if isinstance(v, np.ndarray) and v.shape[0] == 2 else v) for k, v in c.items()}
+        cb["k_codes"], cb["v_codes"] = cb["k_codes"][:, :, :Tb], cb["v_codes"][:, :, :Tb]
+        cb["k_res"][:, :, rb], cb["v_res"][:, :, rb] = k_new[b:b + 1, :, 0], v_new[b:b + 1, :, 0]
+        cb["r"] = rb + 1
+        _check(out[b:b + 1].cpu().numpy(), oracle.decode_attn(**cb), f"request {b}: T={Tb}, appended row {rb}")
+    assert lengths.cpu().numpy()[:, 1].tolist() == [51, 50]
+    assert ops.tail_faults() == 0

@@ -28,6 +28,7 @@ ap.add_argument("--bindings-10arg", action="store_true",
 ap.add_argument("--zero-codes", action="store_true", help="diagnostic: all code bytes 0 (every LDS gather is a broadcast: no bank conflicts)")
 ap.add_argument("--k-conflict-free", action="store_true", help="diagnostic: K codes chosen so that the 64 lanes of every K gather hit 64 different LDS banks (M = 64 streaming kernel)")
 ap.add_argument("--eager-after-sleep", action="store_true", help="rounds 1-3 timing: eager launches enqueued behind a device-side sleep (reads slow: the clocks drop during the sleep)")
+ap.add_argument("--policy", type=int, default=0, help="million_set_force_generic value for the TIMED launches (16: the lean kernel's shapes stay on the streaming kernel)")
 ap.add_argument("--same-page", action="store_true", help="diagnostic: every page id = 0 (codes come from L2, not HBM)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -81,7 +82,7 @@ for cfg in args.cfg:
 
     lib.million_set_force_generic(2 if (d == 128 and M in (32, 64)) else 1)        # grouped kernel (scalar kernel off the streaming shapes) as the cross-check
     ref = run(0).float()
-    lib.million_set_force_generic(0)
+    lib.million_set_force_generic(args.policy)
     out = run(0).float()
     err = ((out - ref).norm() / ref.norm()).item()
     if not (err < 1e-2):      # say where: (request, head) pairs that differ, and whether a merge gave up on a flag
@@ -128,11 +129,13 @@ for cfg in args.cfg:
     if args.vs_scalar:
         lib.million_set_force_generic(1)
         scalar = timed(max(4, args.iters // 8))
-        lib.million_set_force_generic(0)
+        lib.million_set_force_generic(args.policy)
     alg = 2 * bs * nhk * T * M + 2 * bs * nhk * r * d * 2 + 2 * M * C * (d // M) * 2 + bs * nh * d * 4
     if args.bindings_10arg:
         tag = tag + " 10-arg"
     extra = f"   scalar fallback {scalar:8.1f} us ({scalar / best:5.1f}x)" if scalar else ""
+    if args.policy:
+        tag = tag + f" policy {args.policy}"
     print(f"{tag:34s} bs={bs} nh={nh} nh_k={nhk} T={T:6d} d={d} M={M} C={C} kind={kind}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs cross-check {err:.1e}{extra}", flush=True)
     del states
     torch.cuda.empty_cache()
