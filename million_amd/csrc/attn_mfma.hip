@@ -2118,6 +2118,19 @@ struct Unit64 {
     v4u k[4];   // lane t: bytes [16 q, 16 q + 16) of token t's code row
     v4u v[4];   // x = 2 pi + t: lane (kg, n): subspace 32 pi + 16 (t ^ (kg & 1)) + n, tokens 16 kg .. 16 kg + 15
 };
+struct Unit64M32 {      // M = 32
+    v4u k[2];   // lane t: bytes [16 q, 16 q + 16) of token t's 32-byte code row
+    v4u v[2];   // tile t: lane (kg, n): subspace n + 16 t, tokens 16 kg .. 16 kg + 15
+};
+template <int B>
+__device__ __forceinline__ unsigned byte_x8(unsigned w) {      // 8 * byte B of w (8-byte table entries), one SDWA shift
+    unsigned r;
+    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(3u), "v"(w));
+    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(3u), "v"(w));
+    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(3u), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(3u), "v"(w));
+    return r;
+}
 // residual tile: scores on the 16 x 16 x 32 tile as in the streaming kernel (A = the fp16 K rows); values in z-rows:
 // v[2 pi + z][i] = dims (2 m, 2 m + 1), m = 32 pi + 16 z + n, of tile row 4 kg + i - the B operand of the MFMA of (pi, z)
 struct ResTileLean {
@@ -2144,8 +2157,15 @@ __device__ __forceinline__ void load_res_tile_lean(const AttnParams &p, int bh, 
     }
 }
 
-template <int MODE>
+// MS = 64: as described above.  MS = 32 (d_m = 4: a code byte is 4 dims = one k-step; 8-byte table entries): the K side is the same with
+// ONE ds_read_b64 per k-step; the value side is the d_m = 4 form of the streaming kernel (rows = (dim position dq, head): all 16 rows
+// in use already; reduction = (token of 2, dim position of 4); two column tiles of 16 subspaces; lanes (kg, n) and (kg + 1, n) gather
+// the same subspace for different tokens - its 2-way conflict stays) fed by the same swizzle-broadcast pairs: A = the pairs of the
+// step's two tokens ANDed with the lane's dim-position masks.
+template <int MODE, int MS = 64>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
+    static_assert(MS == 64 || MS == 32, "lean kernel: M = 64 or 32");
+    constexpr int kLog2M = MS == 64 ? 6 : 5;
     constexpr int RING = 2;      // ring slots of one 64-token unit (32 registers each).  Three slots (the K bytes two blocks ahead
                                  // instead of one) were measured and are slower at every shape: 24.98 vs 22.65 us at two requests,
                                  // 60.5 vs 59.8 at eight, 67.2 vs 65.1 at 8 x 36864 (profiles/r05_ab_lean.txt)
@@ -2240,46 +2260,50 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     const bool has_res = kResRows * wave < rcnt;
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
-    ResTileLean rt;
-    v8f16 qb[4];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims 32 q4 + 8 s ..)
+    typename std::conditional<MS == 64, ResTileLean, ResTile>::type rt;
+    v8f16 qb[4];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims 32 q4 + 8 s ..; M = 32: head
+                      // c16 & 3 - the four column groups carry copies of the heads, as in the streaming kernel's d_m = 4 form)
     if (has_res) {
-        load_res_tile_lean(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
-        const f16 *qv = qrow + (n16 < G ? n16 : 0) * 128 + 32 * kg;
+        if constexpr (MS == 64) load_res_tile_lean(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+        else load_res_tile<320>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+        const int hq = MS == 64 ? n16 : hj;
+        const f16 *qv = qrow + (hq < G ? hq : 0) * 128 + 32 * kg;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             v4u t = *(const v4u *)(qv + 8 * s);
-            if (n16 >= G) t = v4u{0, 0, 0, 0};
+            if (hq >= G) t = v4u{0, 0, 0, 0};
             qb[s] = __builtin_bit_cast(v8f16, t);
         }
     }
 
     // ---- one unit's 16-byte requests into ring slot SL (rounds past the wave's last unit re-request it: no load in a conditional) ----
-    Unit64 ring[RING];
-    const unsigned k_lane_off = (unsigned)lane << 6;
-    // V: x even reads subspace row 16 (kg & 1) + n, x odd the other 16 of the pair's 32; + 32 subspace rows per pi
-    const unsigned v_lane_off1 = ((unsigned)(n16 + 16 * (kg & 1)) << p.ps_shift) + 16u * kg;
-    const unsigned v_lane_off2 = ((unsigned)(n16 + 16 * (1 - (kg & 1))) << p.ps_shift) + 16u * kg;
+    typename std::conditional<MS == 64, Unit64, Unit64M32>::type ring[RING];
+    const unsigned k_lane_off = (unsigned)lane << kLog2M;
+    // V, M = 64: x even reads subspace row 16 (kg & 1) + n, x odd the other 16 of the pair's 32; + 32 subspace rows per pi
+    //    M = 32: tile t reads subspace row n + 16 t
+    const unsigned v_lane_off1 = ((unsigned)(n16 + (MS == 64 ? 16 * (kg & 1) : 0)) << p.ps_shift) + 16u * kg;
+    const unsigned v_lane_off2 = ((unsigned)(n16 + (MS == 64 ? 16 * (1 - (kg & 1)) : 16)) << p.ps_shift) + 16u * kg;
 #define UNIT_REQ_K(SL, J)                                                                                          \
     {                                                                                                              \
         const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
         gptr_u8 kb_;                                                                                               \
         if (k_paged) {                                                                                             \
             const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
-            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << 6));                                     \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + k_lane_off + 16u * q_); \
+            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << kLog2M));                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < MS / 16; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + k_lane_off + 16u * q_); \
         } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
             const int tu_ = t0 + jc_ * t_step;                                                                     \
             kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
-            const unsigned ro_ = (unsigned)min(tu_ + lane, T_ld - 1) << 6;                                         \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + ro_ + 16u * q_);   \
+            const unsigned ro_ = (unsigned)min(tu_ + lane, T_ld - 1) << kLog2M;                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < MS / 16; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + ro_ + 16u * q_); \
         }                                                                                                          \
     }
 #define UNIT_REQ_V(SL, J)                                                                                          \
     {                                                                                                              \
         const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
         const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
-        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (6 + p.ps_shift)) + tin);                              \
-        _Pragma("unroll") for (int x_ = 0; x_ < 4; ++x_)                                                           \
+        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + p.ps_shift)) + tin);                         \
+        _Pragma("unroll") for (int x_ = 0; x_ < MS / 16; ++x_)                                                     \
             ring[SL].v[x_] = *(gptr_v4u)(vb_ + ((x_ & 1) ? v_lane_off2 : v_lane_off1) + ((32u * (x_ >> 1)) << p.ps_shift)); \
     }
 #define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
@@ -2314,7 +2338,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     const unsigned zr_half = ((lane >> 2) & 1) ? 0xffff0000u : 0x0000ffffu;
     const bool z_own = (kg & 1) == ((lane >> 3) & 1);
     const unsigned zmask0 = z_own ? zr_half : 0u, zmask1 = z_own ? 0u : zr_half;
-    const unsigned vcz0 = (unsigned)kVBase | ((unsigned)(n16 + 16 * (kg & 1)) << 2), vcz1 = (unsigned)kVBase | ((unsigned)(n16 + 16 * (1 - (kg & 1))) << 2);
+    const unsigned vcz0 = MS == 64 ? ((unsigned)kVBase | ((unsigned)(n16 + 16 * (kg & 1)) << 2)) : ((unsigned)kVBase | ((unsigned)n16 << 3));      // M = 32: base | 8 n
+    const unsigned vcz1 = (unsigned)kVBase | ((unsigned)(n16 + 16 * (1 - (kg & 1))) << 2);
+    unsigned d4mx, d4my;          // M = 32: the half of the A-operand registers this lane's rows (dim position dq = bits 3:2) take their pair in
+    d8_masks(lane, d4mx, d4my);
     const float c_ = p.scale_log2e, inv_c = 1.0f / p.scale_log2e;
     const float idle = hj < G ? 0.f : -INFINITY;      // lanes of heads that do not exist: probabilities come out as exact zeros
     // softmax state of head (lane & 3): the reference m (see SoftRef), this lane's part of the row sums
@@ -2323,6 +2350,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         float scr[4], m_run = -INFINITY, l_run = 0.f;
         score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);      // lane (q4, head c16): rows 4 q4 + rho
         softmax_online<4, false>(scr, m_run, l_run, O, G, lane);           // O is zero: nothing is rescaled
+        if constexpr (MS == 32) {      // every lane holds its own head's probabilities (replicated column groups) and reference
+            value_res_tile_d4(rt, scr, d4mx, d4my, O);
+            s_m = m_run;
+            s_l = (lane & 12) == 0 ? l_run : 0.f;
+        } else {
         // (P, P) of lanes 0-3 of every 16-lane row (heads 0-3, rows 4 kg + i) -> the whole row; rows of z: one product per (pi, z)
         unsigned sw_[4];
 #pragma unroll
@@ -2340,6 +2372,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         // state into the lean layout: head j's reference sits in lane j of every row (bank 0); a row's sums are counted once
         s_m = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, m_run), 0x13));
         s_l = (lane & 12) == 0 ? l_run : 0.f;
+        }
     }
     STAMP(2);
     float s_neg = (s_m > -INFINITY ? -s_m : 0.f) + idle, s_thr = (s_m + 8.0f) * inv_c;
@@ -2352,12 +2385,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     v4f32 D[2];
 
     // ---- K side: k-step sg = subspaces 2 sigma, 2 sigma + 1 (wave-uniform: the table base is the read's offset field) ----
-#define KBYTE4(SL, B) byte_x4<(B) & 3>(ring[SL].k[(B) >> 4][((B) >> 2) & 3])      /* 4 * code byte B of the lane's row */
+#define KBYTE4(SL, B) byte_x4<(B) & 3>(ring[SL].k[((B) >> 4) & (MS / 16 - 1)][((B) >> 2) & 3])      /* 4 * code byte B of the lane's row */
 #define LEAN_SIGMA(SG) (8 * ((SG) >> 3) + 2 * ((SG) & 3) + (((SG) >> 2) & 1))
+#define KBYTE8(SL, B) byte_x8<(B) & 3>(ring[SL].k[((B) >> 4) & (MS / 16 - 1)][((B) >> 2) & 3])      /* 8 * code byte B (M = 32) */
 #define KG(SL, SG)                                                                                                 \
     {                                                                                                              \
-        a[(SG) & 7][0] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG)) + (2 * LEAN_SIGMA(SG)) * 1024u);                     \
-        a[(SG) & 7][1] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG) + 1) + (2 * LEAN_SIGMA(SG) + 1) * 1024u);             \
+        if constexpr (MS == 64) {                                                                                  \
+            a[(SG) & 7][0] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG)) + (2 * LEAN_SIGMA(SG)) * 1024u);                 \
+            a[(SG) & 7][1] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG) + 1) + (2 * LEAN_SIGMA(SG) + 1) * 1024u);         \
+        } else {      /* M = 32: k-step = subspace LEAN_SIGMA(SG): one 8-byte entry = the lane's 4 dims */           \
+            a[(SG) & 7] = lds64(KBYTE8(SL, LEAN_SIGMA(SG)) + LEAN_SIGMA(SG) * 2048u);                              \
+        }                                                                                                          \
     }
     // (the empty asm behind a product pins it: an MFMA is register-only, so hipcc moves it across sched_barrier() at will - it
     // bunched the score products in runs of 4-12 behind runs of 4-5 value products; with its accumulator made opaque at this
@@ -2370,24 +2408,39 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     }
     // ---- V side: value step i = 4 s + 2 phi + pi (consecutive products alternate between the two accumulators): gathers from
     //      ring.v[2 pi + phi], dword s (tokens 16 kg + 4 s + 0..3) ----
+    //      M = 32: value step i = 4 s + 2 h + t: tokens 16 kg + 4 s + 2 h + 0..1 (bytes 2 h, 2 h + 1 of dword s of ring.v[t]), column tile t
 #define VG(SL, I)                                                                                                  \
     {                                                                                                              \
-        const unsigned w_ = ring[SL].v[2 * ((I) & 1) + (((I) >> 1) & 1)][(I) >> 2];                                \
-        const unsigned vc_ = ((I) & 2) ? vcz1 : vcz0;                                                              \
-        e[(I) & 3][0] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020400u) + 128u * ((I) & 1));                     \
-        e[(I) & 3][1] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020500u) + 128u * ((I) & 1));                     \
-        e[(I) & 3][2] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020600u) + 128u * ((I) & 1));                     \
-        e[(I) & 3][3] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020700u) + 128u * ((I) & 1));                     \
+        if constexpr (MS == 64) {                                                                                  \
+            const unsigned w_ = ring[SL].v[(2 * ((I) & 1) + (((I) >> 1) & 1)) & (MS / 16 - 1)][(I) >> 2];          \
+            const unsigned vc_ = ((I) & 2) ? vcz1 : vcz0;                                                          \
+            e[(I) & 3][0] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020400u) + 128u * ((I) & 1));                 \
+            e[(I) & 3][1] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020500u) + 128u * ((I) & 1));                 \
+            e[(I) & 3][2] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020600u) + 128u * ((I) & 1));                 \
+            e[(I) & 3][3] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020700u) + 128u * ((I) & 1));                 \
+        } else {                                                                                                   \
+            const unsigned w_ = ring[SL].v[(I) & 1][(I) >> 2];                                                     \
+            const v2u x0_ = lds64(__builtin_amdgcn_perm(w_, vcz0, ((I) & 2) ? 0x03020600u : 0x03020400u) + 128u * ((I) & 1)); \
+            const v2u x1_ = lds64(__builtin_amdgcn_perm(w_, vcz0, ((I) & 2) ? 0x03020700u : 0x03020500u) + 128u * ((I) & 1)); \
+            e[(I) & 3][0] = x0_[0]; e[(I) & 3][1] = x0_[1]; e[(I) & 3][2] = x1_[0]; e[(I) & 3][3] = x1_[1];        \
+        }                                                                                                          \
     }
     // (P, P) of lane bank s -> every lane of the 16-lane row (bit mode: lane' = (lane & 0x13) | (s << 2))
 #define ZSWZ(S) { _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) sw[(S) & 1][ii] = (unsigned)__builtin_amdgcn_ds_swizzle((int)L[ii], 0x13 | (((S) << 2) << 5)); }
 #define VS(I)                                                                                                      \
     {                                                                                                              \
-        if (((I) & 3) == 0) {                                                                                      \
-            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) { Az[0][ii] = sw[((I) >> 2) & 1][ii] & zmask0; Az[1][ii] = sw[((I) >> 2) & 1][ii] & zmask1; } \
-            if ((I) < 12) ZSWZ(((I) >> 2) + 1)                                                                     \
+        if constexpr (MS == 64) {                                                                                  \
+            if (((I) & 3) == 0) {                                                                                  \
+                _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) { Az[0][ii] = sw[((I) >> 2) & 1][ii] & zmask0; Az[1][ii] = sw[((I) >> 2) & 1][ii] & zmask1; } \
+                if ((I) < 12) ZSWZ(((I) >> 2) + 1)                                                                 \
+            }                                                                                                      \
+        } else if (((I) & 1) == 0) {      /* M = 32: the A operand of the step's two tokens (pairs 2 h, 2 h + 1 of block s), for both tiles */ \
+            Az[0][0] = sw[((I) >> 2) & 1][(I) & 2] & d4mx; Az[0][1] = sw[((I) >> 2) & 1][(I) & 2] & d4my;          \
+            Az[0][2] = sw[((I) >> 2) & 1][((I) & 2) + 1] & d4mx; Az[0][3] = sw[((I) >> 2) & 1][((I) & 2) + 1] & d4my; \
+            if (((I) & 3) == 2 && (I) < 12) ZSWZ(((I) >> 2) + 1)                                                   \
         }                                                                                                          \
-        O.t[(I) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(Az[((I) >> 1) & 1][0], Az[((I) >> 1) & 1][1], Az[((I) >> 1) & 1][2], Az[((I) >> 1) & 1][3]), \
+        constexpr int az_ = MS == 64 ? (((I) >> 1) & 1) : 0;                                                       \
+        O.t[(I) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(Az[az_][0], Az[az_][1], Az[az_][2], Az[az_][3]), \
                                                               as_v8f16(e[(I) & 3][0], e[(I) & 3][1], e[(I) & 3][2], e[(I) & 3][3]), \
                                                               O.t[(I) & 1], 0, 0, 0);                              \
         asm volatile("" : "+v"(O.t[(I) & 1]));                                                                     \
@@ -2533,6 +2586,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
 #undef KG
 #undef LEAN_SIGMA
 #undef KBYTE4
+#undef KBYTE8
 #undef UNIT_REQ
 #undef UNIT_REQ_K
 #undef UNIT_REQ_V
@@ -2541,7 +2595,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     float l_row = s_l;
     l_row += MILLION_DPP(l_row, 0x124);
     l_row += MILLION_DPP(l_row, 0x128);
-    merge_and_publish<640, false>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, s_m, l_row, treq);
+    merge_and_publish<(MS == 64 ? 640 : 320), false>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, s_m, l_row, treq);
 #undef STAMP
 }
 
@@ -2673,6 +2727,9 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
@@ -2693,6 +2750,10 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
             if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1>), grid, block, kLdsBytes, s, p);
             else hipLaunchKernelGGL((attn_lean_kernel<2>), grid, block, kLdsBytes, s, p);
+        } else if (p.M == 32 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && !(g_mfma_form & 1)) {      // lean kernel, d_m = 4
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 32>), grid, block, kLdsBytes, s, p);
         } else if (p.M == 64) {
             if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<64, 0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<64, 1>), grid, block, kLdsBytes, s, p);

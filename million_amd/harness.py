@@ -352,7 +352,7 @@ class GraphedPQDecoder:
 
 def speedtest(*, ctx=32768, decode=10, niter=5, bs=1, model="llama31_8b", layers=None,
               backends=("hf_baseline", "static_fp16", "pq_eager", "pq_graph"), prefill=True, breakdown=False,
-              ttft_iters=2, device=None, log=None, deadline=None):
+              ttft_iters=2, device=None, log=None, deadline=None, M=64):
     """The reference's speed test (scripts/benchmarks/speedtest.py:85-117) on a Llama-shaped random-weight model: one
     warm-up generation, then `niter` timed ones of `decode` tokens; every generated token is handed to the host (the
     reference's streamer), the wall-clock interval between consecutive tokens is recorded, TPOT = sum(intervals[1:]) /
@@ -369,7 +369,7 @@ def speedtest(*, ctx=32768, decode=10, niter=5, bs=1, model="llama31_8b", layers
     net = LlamaShapeDecoder(shape, device)
     dl = decode
     max_new = (niter + 2) * dl + 16
-    results = {"config": {"model": model, "ctx": ctx, "decoding_length": dl, "niter": niter, "bs": bs,
+    results = {"config": {"model": model, "ctx": ctx, "decoding_length": dl, "niter": niter, "bs": bs, "pq_M": M,
                           "layers": shape.n_layers, "weights": "random fp16", "prompt": "random ids" if prefill else "synthetic cache fill",
                           "tpot": "speedtest.py:104 definition: mean inter-token interval, the first (prompt) interval excluded"}}
 
@@ -395,7 +395,7 @@ def speedtest(*, ctx=32768, decode=10, niter=5, bs=1, model="llama31_8b", layers
         if name == "static_fp16":
             return StaticFP16Cache(shape, bs, ctx, max_new, device)
         if name in ("pq_eager", "pq_graph"):
-            return PQBackend(shape, bs, ctx, max_new, device, synthetic_fill=filled)
+            return PQBackend(shape, bs, ctx, max_new, device, M=M, synthetic_fill=filled)
         raise ValueError(f"unknown backend {name}")
 
     prompt = torch.randint(0, shape.vocab, (bs, ctx), device=device) if prefill else None

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--bs", type=int, default=1)
     ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "llama2_7b"])
     ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--M", type=int, default=64, help="PQ subspaces (BASELINE configs[4]: 32)")
     ap.add_argument("--backends", default="hf_baseline,static_fp16,pq_eager,pq_graph")
     ap.add_argument("--prefill", action="store_true", help="run a real prompt of --ctx tokens through the model: TTFT")
     ap.add_argument("--breakdown", action="store_true", help="per-section cumulative timers over one extra generation")
@@ -48,7 +49,7 @@ def main():
         raise SystemExit("needs an MI355X")
     results = H.speedtest(ctx=args.ctx, decode=args.decode, niter=args.niter, bs=args.bs, model=args.model, layers=args.layers,
                           backends=tuple(args.backends.split(",")), prefill=args.prefill, breakdown=args.breakdown,
-                          ttft_iters=args.niter, log=lambda m: print(m, flush=True))
+                          ttft_iters=args.niter, M=args.M, log=lambda m: print(m, flush=True))
     line = json.dumps(results)
     print(line)
     if args.out:
