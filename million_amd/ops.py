@@ -488,10 +488,17 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
     lengths and extents, which change at every flush, are checked on every call: _check_stores_per_call).
     Threads: a signature (the stream is part of it) must be driven from ONE thread at a time - the plan's descriptor is written
     per call; different streams have different plans and may be driven concurrently."""
-    T = key_codes.shape[2]
+    kshape = key_codes.shape
+    T = kshape[2]
     paged = v_page_ids is not None
     stream = _stream()      # part of the signature: the workspace of a plan belongs to one (device, stream)
-    sig = _plan_signature(stream, query, key_codes, value_codes, key_residuals, value_residuals, v_page_ids, page_size, M, C)
+    # (the tuple of _plan_signature, spelled out: this is the per-call path of an eager harness - a Python call costs ~0.2 us)
+    sig = (stream, query.shape, query.dtype, query.is_contiguous(), kshape[1], key_codes.stride()[2:], key_codes.dtype,
+           value_codes.shape if paged else value_codes.stride()[2:], value_codes.dtype,
+           key_residuals.shape, key_residuals.stride(), key_residuals.dtype, value_residuals.shape, value_residuals.stride(),
+           value_residuals.dtype,
+           (v_page_ids.shape, v_page_ids.dtype, v_page_ids.is_contiguous(), page_size) if paged else None,
+           query.device.index, M, C)
     plan = _plans.get(sig)
     if plan is None:
         if check is not None:
@@ -527,7 +534,13 @@ def decode_attn_planned(query, key_codes, value_codes, key_cents, value_cents, k
         _plans.move_to_end(sig)
     except KeyError:      # another thread's miss path evicted this signature between the lookup and here: the plan in hand is still valid
         pass
-    _check_stores_per_call(query, key_codes, value_codes, T, M, paged)
+    # what the signature cannot vouch for (_check_stores_per_call, inlined): extents of the stores, which change at every flush
+    if len(kshape) != 4 or kshape[0] != query.shape[0] or kshape[3] != M:
+        _check_stores_per_call(query, key_codes, value_codes, T, M, paged)
+    if not paged:
+        vshape = value_codes.shape
+        if len(vshape) != 4 or vshape[0] != kshape[0] or vshape[1] != kshape[1] or vshape[3] != M or vshape[2] < T:
+            _check_stores_per_call(query, key_codes, value_codes, T, M, paged)
     if T <= 0:
         raise RuntimeError("decode_attn_planned: empty code store")      # (never cached: fast_shape needs T > 0)
     r = int(r)

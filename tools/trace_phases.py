@@ -32,7 +32,7 @@ for st, en, name in rows:
     if "sleep" in name.lower() or "spin" in name.lower():
         phases.append([])
         continue
-    if "attn_stream_kernel" in name or "attn_mfma_kernel" in name:
+    if "attn_stream_kernel" in name or "attn_mfma_kernel" in name or "attn_lean_kernel" in name:
         phases[-1].append((st, en))
 names = ["steps (replayed step graphs: fused append, device lengths)"]
 for ph in phases[1:]:
