@@ -837,22 +837,24 @@ __device__ unsigned g_tail_faults = 0;
 // summed with DPP / row swaps.  (A two-heads-per-pass variant - both heads' loads in flight before the first reduction - paid
 // when ONE workgroup merged every head; with the helpers back each merger has one head per wave group and the second
 // instantiation only made the cold tail longer.)
+template <int DD = 128>      // DD = d: rows of 64 dims (lean kernel, d = 64) keep two of the four waves of a head busy
 __device__ __forceinline__ void tail_merge_head(const AttnParams &p, int b, int hk, int g, int part, int ns, const float *src, int lane,
                                                 bool fault) {
+    if (32 * part >= DD) return;      // wave-uniform
     const int q8 = lane & 7, h = lane >> 3;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
     // softmax weights of the splits (lane = split)
     const bool on = lane < ns;
     const int sl = on ? lane : 0;
-    const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + g) * 4, 0, 16));
-    const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * 128 + p.G + g) * 4, 0, 16));
+    const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * DD + g) * 4, 0, 16));
+    const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sl * p.slot_floats + p.G * DD + p.G + g) * 4, 0, 16));
     v4u v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int slot = 8 * k + h;
         const int sc = slot < ns ? slot : ns - 1;                      // clamped: never a conditional load (weight 0)
         if (k < 4 || ns > 32)                                          // wave-uniform: the second half only for more than 32 splits
-            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * 128 + 32 * part + 4 * q8) * 4, 0, 16);
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (sc * p.slot_floats + g * DD + 32 * part + 4 * q8) * 4, 0, 16);
         else
             v[k] = v4u{0, 0, 0, 0};
     }
@@ -881,11 +883,11 @@ __device__ __forceinline__ void tail_merge_head(const AttnParams &p, int b, int 
     if (lane < 8) {
         typedef f16 h4 __attribute__((ext_vector_type(4)));
         const h4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * 128 + 32 * part + 4 * q8) = o;
+        *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk) + g) * DD + 32 * part + 4 * q8) = o;
     }
 }
 
-template <int MS = 64, bool PV = false, class ACC>
+template <int MS = 64, bool PV = false, int DD = 128, class ACC>
 __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *smem, int b, int hk, int split, int G, int tid,
                                                   int lane, int wave, bool dbg_on, ACC &O, float m_run, float l_run, TailReq &treq) {
 #define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
@@ -910,7 +912,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         const bool all_here = __all(cen_v == tail_xcc() + 1u);
         if (lane == 0) tl[3] = all_here ? 1 : 0;
     }
-    const int wstride = G * 128 + 2 * kMaxGMfma;          // floats per wave (G = 16: 65 KiB for the 8 waves, the dead tables' space)
+    const int wstride = G * DD + 2 * kMaxGMfma;           // floats per wave (G = 16: 65 KiB for the 8 waves, the dead tables' space)
     float *scr_l = (float *)smem;
     float *mine = scr_l + wave * wstride;
     {
@@ -919,17 +921,17 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
         if constexpr (MS == 640) {     // lean kernel (z-rows): accumulator pi, lane (rg = lane >> 4, n = lane & 15), register i = head i:
                                        // row 4 rg + i = (z = rg >> 1, parity rg & 1, head i), column n = subspace 32 pi + 16 z + n
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < DD / 64; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < G) mine[i * 128 + 64 * j + 32 * (lane >> 5) + 2 * (lane & 15) + ((lane >> 4) & 1)] = O.t[j][i];
+                    if (i < G) mine[i * DD + 64 * j + 32 * (lane >> 5) + 2 * (lane & 15) + ((lane >> 4) & 1)] = O.t[j][i];
         } else
         if constexpr (MS == 320) {     // d_m = 4 form: column tile j, lane (dq = lane >> 4, n = lane & 15), register i = head i
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < DD / 64; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < G) mine[i * 128 + 4 * ((lane & 15) + 16 * j) + (lane >> 4)] = O.t[j][i];
+                    if (i < G) mine[i * DD + 4 * ((lane & 15) + 16 * j) + (lane >> 4)] = O.t[j][i];
         } else
         if constexpr (MS == 16) {      // d_m = 8 form: row tile h, lane (dq = lane >> 4, n = lane & 15), register i = head i
 #pragma unroll
@@ -965,8 +967,8 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
             }
         }
         if (lane < G) {                                  // lane g: row q' = 0, col g
-            mine[G * 128 + lane] = m_run;
-            mine[G * 128 + kMaxGMfma + lane] = l_run;
+            mine[G * DD + lane] = m_run;
+            mine[G * DD + kMaxGMfma + lane] = l_run;
         }
     }
     __syncthreads();
@@ -974,19 +976,19 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
     // straight from registers with one 16-byte store into this split's workspace slot: plain (stays in this XCD's L2)
     // when the census says every workgroup of this (b, kv head) runs on this XCD, write-through (sc1) otherwise
     const bool same_xcd = tl[3] != 0;
-    const int nsw = (G * 32 + 63) >> 6;                  // waves that store
+    const int nsw = (G * (DD / 4) + 63) >> 6;            // waves that store
     float *dst = slot_ptr(p, b, hk, split);
     {
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, 0x7fffffff, 0x00020000);
-        for (int q = tid; q < G * 32; q += kNW * 64) {
-            const int g = q >> 5;
+        for (int q = tid; q < G * (DD / 4); q += kNW * 64) {
+            const int g = q / (DD / 4);
             float mw[kNW], lw[kNW];
             v4f32 vw[kNW];
 #pragma unroll
             for (int w = 0; w < kNW; ++w) {
-                mw[w] = scr_l[w * wstride + G * 128 + g];
+                mw[w] = scr_l[w * wstride + G * DD + g];
                 vw[w] = *(const v4f32 *)(scr_l + w * wstride + 4 * q);
-                lw[w] = scr_l[w * wstride + G * 128 + kMaxGMfma + g];
+                lw[w] = scr_l[w * wstride + G * DD + kMaxGMfma + g];
             }
             float Mx = mw[0];
 #pragma unroll
@@ -1004,18 +1006,18 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                 const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
                 typedef f16 h4 __attribute__((ext_vector_type(4)));
                 const h4 o = {(f16)(acc[0] * inv), (f16)(acc[1] * inv), (f16)(acc[2] * inv), (f16)(acc[3] * inv)};
-                *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk)) * 128 + 4 * q) = o;
+                *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk)) * DD + 4 * q) = o;
             } else if (same_xcd) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 0);
-                if ((q & 31) == 0) {
-                    dst[G * 128 + g] = Mx;
-                    dst[G * 128 + G + g] = lsum;
+                if (q % (DD / 4) == 0) {
+                    dst[G * DD + g] = Mx;
+                    dst[G * DD + G + g] = lsum;
                 }
             } else {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 16 /* sc1 */);
-                if ((q & 31) == 0) {
-                    st_agent(dst + G * 128 + g, Mx);
-                    st_agent(dst + G * 128 + G + g, lsum);
+                if (q % (DD / 4) == 0) {
+                    st_agent(dst + G * DD + g, Mx);
+                    st_agent(dst + G * DD + G + g, lsum);
                 }
             }
         }
@@ -1101,7 +1103,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                 if (state == 3) break;
                 if (__builtin_expect(state == 2, 0) && lane == 0) atomicAdd(&g_tail_faults, 1u);      // this wave's outputs are written as NaN
             }
-            tail_merge_head(p, b, hk, g, wave & 3, ns, src, lane, state == 2);
+            tail_merge_head<DD>(p, b, hk, g, wave & 3, ns, src, lane, state == 2);
         }
         // the primary also merges the heads of the helpers that gave up before it took its index (bits of its own ticket):
         // heads h, h + nm, ... of helper h, the same four-waves-per-head split
@@ -1120,7 +1122,7 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
             for (int h = 0; h < nm - 1; ++h)
                 if (gave >> h & 1u)
                     for (int g = h; g < G; g += nm) {
-                        if ((pos & 1) == (wave >> 2)) tail_merge_head(p, b, hk, g, wave & 3, ns, src, lane, state == 2);
+                        if ((pos & 1) == (wave >> 2)) tail_merge_head<DD>(p, b, hk, g, wave & 3, ns, src, lane, state == 2);
                         ++pos;
                     }
         }
@@ -2073,531 +2075,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
 #undef STAMP
 }
 
-// =====================================================================================================
-// Lean kernel (round 5): M = 64, C = 256, up to 4 query heads per kv head, pages of 64 or 128 tokens (or row-major K).
-//
-// The streaming kernel above spends its vector issue on PQ address arithmetic (two instructions per K lookup: a lane's table base
-// depends on the lane) and multiplies idle rows / columns (scores: 4 of the 16 head columns of a 16 x 16 x 32 tile, values: 8 of the
-// 32 rows of a 32 x 32 x 16 tile).  This kernel keeps its launch skeleton - page-strided units, ONE page-id vector load, both
-// codebooks in LDS behind one barrier, the residual tile, the fused append, the L2 tail - and replaces the core
-// (tools/micro/lean_core.hip measures it alone: 1.15-1.18 x the units per us and SIMD of the parity-V core on cache-resident
-// codes at +0.26 GHz of in-kernel clock, 1.05-1.14 x streamed from HBM; profiles/r05_core_micro.txt):
-//   * a unit is 64 tokens and LANE = TOKEN on the K side: a lane owns its token's whole 64-byte code row (four 16-byte loads);
-//   * scores by v_mfma_f32_4x4x4_16B_f16 - sixteen independent blocks of 4 tokens x 4 heads x 4 dims: every MAC useful at G = 4.
-//     A = the two gathered centroid words of subspaces (2 s, 2 s + 1) as gathered.  The subspace is wave-uniform, so the table base
-//     rides in the ds_read offset field and a K lookup address is ONE instruction (an SDWA shift of the code byte).  B = the query
-//     heads: eight register pairs; k-step s = 4 u + lambda sits in lane group lambda of pair u and the MFMA's blgp field broadcasts
-//     that group to every block.  The scores land in lane (token quad b, head j), register i = token 4 b + i: all 64 lanes carry
-//     useful scores, the softmax is 4 exponentials per 64 tokens and lane (16 x 16 tiles: 16);
-//   * values by v_mfma_f32_16x16x32_f16 in "z-rows": rows = (z, parity of the dim, head < 4) - all 16 rows in use; the reduction
-//     index is (token, parity) and the gathered V word is the B operand as it stands (as in parity-V).  Row (z, p, g) is fed by the
-//     token groups kg (16 lanes = 16 tokens each) with (kg & 1) == z ^ phi in the MFMA of phase phi, and those lanes gather
-//     subspace 32 pi + 16 z + n: the two token groups of a 32-lane LDS half read two different sets of 16 subspaces - 32 distinct
-//     banks, conflict-free (with rows = (parity, head < 8) both groups read the SAME subspace for different tokens: every V gather
-//     a 2-way conflict, and the core was LDS-bound: micro VAR 0) - phase 1 swaps the roles, both phases accumulate into the same 4
-//     registers: 8 accumulator registers in all (parity-V: 32).  The A operand needs "4 tokens of ONE head" per lane - exactly
-//     what a score lane holds: (P, P) pairs are broadcast from lane bank s to the whole 16-lane row by ONE ds_swizzle per register
-//     and token step and ANDed with a lane-constant mask per phase (half of the dword by parity; zero where the lane's token group
-//     does not feed the row).
-// Per 64 tokens and wave: 128 LDS gathers (as before), 48 MFMAs (32 of them 4 x 4 x 4: 512 matrix-pipe cycles; parity-V: 768),
-// ~215 vector instructions (parity-V: ~300), 16 swizzles.  G > 4, pages of 32 tokens, C = 128 and M != 64 stay on the streaming
-// kernel (million_set_force_generic(16) keeps everything there: A/B and tests).
-// =====================================================================================================
-// 4 * byte B of w - the LDS offset of a 4-byte table entry - in ONE instruction (hipcc finds the SDWA form for bytes 1-3 by itself
-// and emits shift + mask for byte 0)
-template <int B>
-__device__ __forceinline__ unsigned byte_x4(unsigned w) {
-    unsigned r;
-    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(2u), "v"(w));
-    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(2u), "v"(w));
-    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(2u), "v"(w));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(2u), "v"(w));
-    return r;
-}
-struct Unit64 {
-    v4u k[4];   // lane t: bytes [16 q, 16 q + 16) of token t's code row
-    v4u v[4];   // x = 2 pi + t: lane (kg, n): subspace 32 pi + 16 (t ^ (kg & 1)) + n, tokens 16 kg .. 16 kg + 15
-};
-struct Unit64M32 {      // M = 32
-    v4u k[2];   // lane t: bytes [16 q, 16 q + 16) of token t's 32-byte code row
-    v4u v[2];   // tile t: lane (kg, n): subspace n + 16 t, tokens 16 kg .. 16 kg + 15
-};
-template <int B>
-__device__ __forceinline__ unsigned byte_x8(unsigned w) {      // 8 * byte B of w (8-byte table entries), one SDWA shift
-    unsigned r;
-    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(3u), "v"(w));
-    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(3u), "v"(w));
-    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(3u), "v"(w));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(3u), "v"(w));
-    return r;
-}
-// residual tile: scores on the 16 x 16 x 32 tile as in the streaming kernel (A = the fp16 K rows); values in z-rows:
-// v[2 pi + z][i] = dims (2 m, 2 m + 1), m = 32 pi + 16 z + n, of tile row 4 kg + i - the B operand of the MFMA of (pi, z)
-struct ResTileLean {
-    v4u k[4];
-    unsigned v[4][4];
-};
-__device__ __forceinline__ void load_res_tile_lean(const AttnParams &p, int bh, const f16 *kr, const f16 *vr, int wave, int rcnt,
-                                                   int split, int rstart, int r_old, int lane, ResTileLean &t) {
-    const int q4 = lane >> 4, c16 = lane & 15;
-    {
-        bool is_new;
-        const long long off = res_row_off(p, kResRows * wave + c16, wave, rcnt, split, rstart, r_old, is_new);
-        const f16 *kp = (is_new ? p.k_new + (long long)bh * 128 : kr + off) + 32 * q4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bool is_new;
-        const long long off = res_row_off(p, kResRows * wave + 4 * q4 + i, wave, rcnt, split, rstart, r_old, is_new);
-        const f16 *vp = (is_new ? p.v_new + (long long)bh * 128 : vr + off) + 2 * c16;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) t.v[x][i] = *(const unsigned *)(vp + 32 * x);      // dims 2 (16 x + n): x = 2 pi + z
-    }
-}
-
-// MS = 64: as described above.  MS = 32 (d_m = 4: a code byte is 4 dims = one k-step; 8-byte table entries): the K side is the same with
-// ONE ds_read_b64 per k-step; the value side is the d_m = 4 form of the streaming kernel (rows = (dim position dq, head): all 16 rows
-// in use already; reduction = (token of 2, dim position of 4); two column tiles of 16 subspaces; lanes (kg, n) and (kg + 1, n) gather
-// the same subspace for different tokens - its 2-way conflict stays) fed by the same swizzle-broadcast pairs: A = the pairs of the
-// step's two tokens ANDed with the lane's dim-position masks.
-template <int MODE, int MS = 64>
-__global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
-    static_assert(MS == 64 || MS == 32, "lean kernel: M = 64 or 32");
-    constexpr int kLog2M = MS == 64 ? 6 : 5;
-    constexpr int RING = 2;      // ring slots of one 64-token unit (32 registers each).  Three slots (the K bytes two blocks ahead
-                                 // instead of one) were measured and are slower at every shape: 24.98 vs 22.65 us at two requests,
-                                 // 60.5 vs 59.8 at eight, 67.2 vs 65.1 at 8 x 36864 (profiles/r05_ab_lean.txt)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int split = blockIdx.x, bh = blockIdx.y;      // all splits of a (b, kv head) on one XCD: see attn_stream_kernel
-    if ((gridDim.y & 7) == 0) {
-        const int id = blockIdx.y * gridDim.x + blockIdx.x;
-        bh = id % (int)gridDim.y;
-        split = id / (int)gridDim.y;
-    }
-    const int b = bh / p.nh_k, hk = bh % p.nh_k;
-    const int G = p.G;
-    const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
-    const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
-    const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i dl = {p.T, p.r, p.rstart, 0};
-    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap();
-    const bool dbg_on = p.dbg != nullptr;
-#define STAMP(i) stamp_lds(dbg_on, lane, wave, i)
-    stamp_lds_clear(dbg_on, lane, wave);
-    STAMP(0);
-    const int kg = lane >> 4, n16 = lane & 15, hj = lane & 3;
-
-    // ---- where this wave reads: page pg0 + j * pg_step in round j, tokens [tin, tin + 64) of it ----
-    const int ups = p.ps_shift - 6;                       // log2(units per page): pages of 64 or 128 tokens
-    const int wp = wave >> ups, uw = wave & ((1 << ups) - 1);
-    const int pg0 = wp * p.nsplit + split;
-    const int pg_step = p.nsplit << (3 - ups);
-    const int tin = uw << 6;
-    int vpk = 0, vpv = 0;      // page ids of rounds 0..63 (lane = round): the oldest loads of the wave
-    {
-        int pgl = pg0 + lane * pg_step;
-        pgl = pgl < p.n_pages_cap ? pgl : p.n_pages_cap - 1;
-        const long long idx = (long long)bh * p.n_pages_cap + pgl;
-        if (k_paged) vpk = ids64 ? (int)p.k_ids64[idx] : p.k_ids32[idx];
-        if (v_ident) vpv = (int)idx;
-        else vpv = ids64 ? (int)p.v_ids64[idx] : p.v_ids32[idx];
-#ifdef MILLION_DEBUG_CHECK_IDS
-        {
-            const bool live = pg0 + lane * pg_step < p.n_pages_cap && ((long long)(pg0 + lane * pg_step) << p.ps_shift) < p.T;
-            if (k_paged) vpk = MILLION_CHECK_KID(p, ids64 ? (long long)p.k_ids64[idx] : (long long)vpk, live);
-            if (!v_ident) vpv = MILLION_CHECK_VID(p, ids64 ? (long long)p.v_ids64[idx] : (long long)vpv, live);
-        }
-#endif
-    }
-    // query operand of the 4 x 4 x 4 products: register pair u, lane group kg holds the 4 dims of k-step (u, kg) of head (lane & 3).
-    // A lane's pairs 2 v, 2 v + 1 are ONE 16-byte load (dims 32 v + 8 kg .. + 7), so k-step (u, lambda) covers subspaces
-    // 2 sigma, 2 sigma + 1 with sigma = 8 (u >> 1) + 2 lambda + (u & 1) (LEAN_SIGMA below): any order of the subspaces will do
-    const f16 *qrow = p.q + ((long long)b * p.nh + head0(p, hk)) * 128;
-    v2u Q[8];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        v4u t = *(const v4u *)(qrow + (hj < G ? hj : 0) * 128 + 32 * v + 8 * kg);
-        if (hj >= G) t = v4u{0, 0, 0, 0};
-        Q[2 * v] = v2u{t[0], t[1]};
-        Q[2 * v + 1] = v2u{t[2], t[3]};
-    }
-    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
-    h2 new_k = {}, new_v = {};
-    if (append_wave) {
-        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
-        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
-    }
-    constexpr int NT = 8;
-    v4u tabk[NT], tabv[NT];
-    const int rot = (blockIdx.x + 5 * blockIdx.y) & 7;
-    {
-        const v4u *ks = (const v4u *)p.k_tab;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) tabk[i] = ks[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
-        const v4u *vs = (const v4u *)p.v_tab_col;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) tabv[i] = vs[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
-    }
-    if (p.dev_lengths)
-        asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
-    int T = dl[0], r_old = dl[1], rstart = dl[2];
-    clamp_lengths(p, T, r_old, rstart);
-    const int r = r_old + (p.k_new ? 1 : 0);
-    const int t0 = (pg0 << p.ps_shift) + tin;             // first token of round 0
-    const int t_step = pg_step << p.ps_shift;             // tokens between rounds
-    const int n_mine = T > t0 ? (T - t0 + t_step - 1) / t_step : 0;      // rounds (= units) of this wave; host: <= 64
-    const int j_last = n_mine > 0 ? n_mine - 1 : 0;
-    const int T_ld = T > 0 ? T : 1;
-
-    // ---- residual window rows of this split (see load_res_tile) ----
-    const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
-    const bool has_res = kResRows * wave < rcnt;
-    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
-    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
-    typename std::conditional<MS == 64, ResTileLean, ResTile>::type rt;
-    v8f16 qb[4];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims 32 q4 + 8 s ..; M = 32: head
-                      // c16 & 3 - the four column groups carry copies of the heads, as in the streaming kernel's d_m = 4 form)
-    if (has_res) {
-        if constexpr (MS == 64) load_res_tile_lean(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
-        else load_res_tile<320>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
-        const int hq = MS == 64 ? n16 : hj;
-        const f16 *qv = qrow + (hq < G ? hq : 0) * 128 + 32 * kg;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            v4u t = *(const v4u *)(qv + 8 * s);
-            if (hq >= G) t = v4u{0, 0, 0, 0};
-            qb[s] = __builtin_bit_cast(v8f16, t);
-        }
-    }
-
-    // ---- one unit's 16-byte requests into ring slot SL (rounds past the wave's last unit re-request it: no load in a conditional) ----
-    typename std::conditional<MS == 64, Unit64, Unit64M32>::type ring[RING];
-    const unsigned k_lane_off = (unsigned)lane << kLog2M;
-    // V, M = 64: x even reads subspace row 16 (kg & 1) + n, x odd the other 16 of the pair's 32; + 32 subspace rows per pi
-    //    M = 32: tile t reads subspace row n + 16 t
-    const unsigned v_lane_off1 = ((unsigned)(n16 + (MS == 64 ? 16 * (kg & 1) : 0)) << p.ps_shift) + 16u * kg;
-    const unsigned v_lane_off2 = ((unsigned)(n16 + (MS == 64 ? 16 * (1 - (kg & 1)) : 16)) << p.ps_shift) + 16u * kg;
-#define UNIT_REQ_K(SL, J)                                                                                          \
-    {                                                                                                              \
-        const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
-        gptr_u8 kb_;                                                                                               \
-        if (k_paged) {                                                                                             \
-            const long long pk_ = (long long)__builtin_amdgcn_readlane(vpk, jc_);                                  \
-            kb_ = uniform_ptr(p.k_codes + (((pk_ << p.ps_shift) + tin) << kLog2M));                                \
-            _Pragma("unroll") for (int q_ = 0; q_ < MS / 16; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + k_lane_off + 16u * q_); \
-        } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
-            const int tu_ = t0 + jc_ * t_step;                                                                     \
-            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
-            const unsigned ro_ = (unsigned)min(tu_ + lane, T_ld - 1) << kLog2M;                                    \
-            _Pragma("unroll") for (int q_ = 0; q_ < MS / 16; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + ro_ + 16u * q_); \
-        }                                                                                                          \
-    }
-#define UNIT_REQ_V(SL, J)                                                                                          \
-    {                                                                                                              \
-        const int jc_ = (J) < n_mine ? (J) : j_last;                                                               \
-        const long long pv_ = (long long)__builtin_amdgcn_readlane(vpv, jc_);                                      \
-        const gptr_u8 vb_ = uniform_ptr(p.v_codes + (pv_ << (kLog2M + p.ps_shift)) + tin);                         \
-        _Pragma("unroll") for (int x_ = 0; x_ < MS / 16; ++x_)                                                     \
-            ring[SL].v[x_] = *(gptr_v4u)(vb_ + ((x_ & 1) ? v_lane_off2 : v_lane_off1) + ((32u * (x_ >> 1)) << p.ps_shift)); \
-    }
-#define UNIT_REQ(SL, J) { UNIT_REQ_K(SL, J) UNIT_REQ_V(SL, J) }
-    // only unit 0 (8 KiB per wave - what the streaming kernel asks for up front) goes out before the codebooks are in LDS: the CU's
-    // request queue is in order, and what is asked for in front of the barrier delays it (both units up front: +1.3 us at one request)
-    UNIT_REQ(0, 0)
-    STAMP(7);
-    {
-        v4u *ld = (v4u *)smem;
-        v4u *ldv = (v4u *)(smem + kVBase);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) ld[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabk[i];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) ldv[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabv[i];
-    }
-    STAMP(8);
-    __syncthreads();
-    STAMP(1);
-
-    Acc8 O;      // O.t[pi][g]: lane (rg, n): head g, dim 64 pi + 32 (rg >> 1) + 2 n + (rg & 1)
-    O.t[0] = v4f32{0.f, 0.f, 0.f, 0.f};
-    O.t[1] = v4f32{0.f, 0.f, 0.f, 0.f};
-    if (append_wave) {
-        int row_n = rstart + r_old;
-        row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
-        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
-        *(h2 *)(p.k_res_w + o) = new_k;
-        *(h2 *)(p.v_res_w + o) = new_v;
-    }
-    // lane constants of the value side: the half of a (P, P) pair this lane's row takes (parity p = bit 2 of the lane), the phase
-    // masks (row z = bit 3 is fed by this lane's token group kg in phase phi iff (kg & 1) == z ^ phi), the gather constants
-    const unsigned zr_half = ((lane >> 2) & 1) ? 0xffff0000u : 0x0000ffffu;
-    const bool z_own = (kg & 1) == ((lane >> 3) & 1);
-    const unsigned zmask0 = z_own ? zr_half : 0u, zmask1 = z_own ? 0u : zr_half;
-    const unsigned vcz0 = MS == 64 ? ((unsigned)kVBase | ((unsigned)(n16 + 16 * (kg & 1)) << 2)) : ((unsigned)kVBase | ((unsigned)n16 << 3));      // M = 32: base | 8 n
-    const unsigned vcz1 = (unsigned)kVBase | ((unsigned)(n16 + 16 * (1 - (kg & 1))) << 2);
-    unsigned d4mx, d4my;          // M = 32: the half of the A-operand registers this lane's rows (dim position dq = bits 3:2) take their pair in
-    d8_masks(lane, d4mx, d4my);
-    const float c_ = p.scale_log2e, inv_c = 1.0f / p.scale_log2e;
-    const float idle = hj < G ? 0.f : -INFINITY;      // lanes of heads that do not exist: probabilities come out as exact zeros
-    // softmax state of head (lane & 3): the reference m (see SoftRef), this lane's part of the row sums
-    float s_m = -INFINITY, s_l = 0.f;
-    if (has_res) {      // residual tile of this wave first: it needs neither codebook
-        float scr[4], m_run = -INFINITY, l_run = 0.f;
-        score_res_tile(rt, qb, p.scale_log2e, wave, rcnt, lane, scr);      // lane (q4, head c16): rows 4 q4 + rho
-        softmax_online<4, false>(scr, m_run, l_run, O, G, lane);           // O is zero: nothing is rescaled
-        if constexpr (MS == 32) {      // every lane holds its own head's probabilities (replicated column groups) and reference
-            value_res_tile_d4(rt, scr, d4mx, d4my, O);
-            s_m = m_run;
-            s_l = (lane & 12) == 0 ? l_run : 0.f;
-        } else {
-        // (P, P) of lanes 0-3 of every 16-lane row (heads 0-3, rows 4 kg + i) -> the whole row; rows of z: one product per (pi, z)
-        unsigned sw_[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const h2 pp = {(f16)scr[i], (f16)scr[i]};
-            sw_[i] = (unsigned)__builtin_amdgcn_ds_swizzle((int)__builtin_bit_cast(unsigned, pp), 0x13);
-        }
-        const unsigned rz0 = ((lane >> 3) & 1) ? 0u : zr_half, rz1 = ((lane >> 3) & 1) ? zr_half : 0u;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const unsigned mk = (x & 1) ? rz1 : rz0;
-            O.t[x >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(sw_[0] & mk, sw_[1] & mk, sw_[2] & mk, sw_[3] & mk),
-                                                                 as_v8f16(rt.v[x][0], rt.v[x][1], rt.v[x][2], rt.v[x][3]), O.t[x >> 1], 0, 0, 0);
-        }
-        // state into the lean layout: head j's reference sits in lane j of every row (bank 0); a row's sums are counted once
-        s_m = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, m_run), 0x13));
-        s_l = (lane & 12) == 0 ? l_run : 0.f;
-        }
-    }
-    STAMP(2);
-    float s_neg = (s_m > -INFINITY ? -s_m : 0.f) + idle, s_thr = (s_m + 8.0f) * inv_c;
-
-    unsigned L[4];                  // (P, P) pairs of this lane's (token quad, head)
-    unsigned sw[2][4];              // the pairs of token step s, broadcast over the 16-lane row (sw[s & 1])
-    unsigned Az[2][4];              // A operands of the two phases
-    v2u a[8];                       // K gathers in flight (k-step sg in a[sg & 7]: 3 steps ahead inside a block, 6 when the scores run alone)
-    unsigned e[4][4];               // V gathers in flight (value step i in e[i & 3]: 2 steps ahead inside a block, 3 alone)
-    v4f32 D[2];
-
-    // ---- K side: k-step sg = subspaces 2 sigma, 2 sigma + 1 (wave-uniform: the table base is the read's offset field) ----
-#define KBYTE4(SL, B) byte_x4<(B) & 3>(ring[SL].k[((B) >> 4) & (MS / 16 - 1)][((B) >> 2) & 3])      /* 4 * code byte B of the lane's row */
-#define LEAN_SIGMA(SG) (8 * ((SG) >> 3) + 2 * ((SG) & 3) + (((SG) >> 2) & 1))
-#define KBYTE8(SL, B) byte_x8<(B) & 3>(ring[SL].k[((B) >> 4) & (MS / 16 - 1)][((B) >> 2) & 3])      /* 8 * code byte B (M = 32) */
-#define KG(SL, SG)                                                                                                 \
-    {                                                                                                              \
-        if constexpr (MS == 64) {                                                                                  \
-            a[(SG) & 7][0] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG)) + (2 * LEAN_SIGMA(SG)) * 1024u);                 \
-            a[(SG) & 7][1] = lds32(KBYTE4(SL, 2 * LEAN_SIGMA(SG) + 1) + (2 * LEAN_SIGMA(SG) + 1) * 1024u);         \
-        } else {      /* M = 32: k-step = subspace LEAN_SIGMA(SG): one 8-byte entry = the lane's 4 dims */           \
-            a[(SG) & 7] = lds64(KBYTE8(SL, LEAN_SIGMA(SG)) + LEAN_SIGMA(SG) * 2048u);                              \
-        }                                                                                                          \
-    }
-    // (the empty asm behind a product pins it: an MFMA is register-only, so hipcc moves it across sched_barrier() at will - it
-    // bunched the score products in runs of 4-12 behind runs of 4-5 value products; with its accumulator made opaque at this
-    // point the product stays in the slot it is written in, cdna_hip_programming.md 5.7 item 3)
-#define KM(SG)                                                                                                     \
-    {                                                                                                              \
-        D[(SG) & 1] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4f16_t, a[(SG) & 7]), __builtin_bit_cast(v4f16_t, Q[(SG) >> 2]), \
-                                                         (SG) < 2 ? v4f32{0.f, 0.f, 0.f, 0.f} : D[(SG) & 1], 0, 0, 4 + ((SG) & 3)); \
-        asm volatile("" : "+v"(D[(SG) & 1]));                                                                      \
-    }
-    // ---- V side: value step i = 4 s + 2 phi + pi (consecutive products alternate between the two accumulators): gathers from
-    //      ring.v[2 pi + phi], dword s (tokens 16 kg + 4 s + 0..3) ----
-    //      M = 32: value step i = 4 s + 2 h + t: tokens 16 kg + 4 s + 2 h + 0..1 (bytes 2 h, 2 h + 1 of dword s of ring.v[t]), column tile t
-#define VG(SL, I)                                                                                                  \
-    {                                                                                                              \
-        if constexpr (MS == 64) {                                                                                  \
-            const unsigned w_ = ring[SL].v[(2 * ((I) & 1) + (((I) >> 1) & 1)) & (MS / 16 - 1)][(I) >> 2];          \
-            const unsigned vc_ = ((I) & 2) ? vcz1 : vcz0;                                                          \
-            e[(I) & 3][0] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020400u) + 128u * ((I) & 1));                 \
-            e[(I) & 3][1] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020500u) + 128u * ((I) & 1));                 \
-            e[(I) & 3][2] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020600u) + 128u * ((I) & 1));                 \
-            e[(I) & 3][3] = lds32(__builtin_amdgcn_perm(w_, vc_, 0x03020700u) + 128u * ((I) & 1));                 \
-        } else {                                                                                                   \
-            const unsigned w_ = ring[SL].v[(I) & 1][(I) >> 2];                                                     \
-            const v2u x0_ = lds64(__builtin_amdgcn_perm(w_, vcz0, ((I) & 2) ? 0x03020600u : 0x03020400u) + 128u * ((I) & 1)); \
-            const v2u x1_ = lds64(__builtin_amdgcn_perm(w_, vcz0, ((I) & 2) ? 0x03020700u : 0x03020500u) + 128u * ((I) & 1)); \
-            e[(I) & 3][0] = x0_[0]; e[(I) & 3][1] = x0_[1]; e[(I) & 3][2] = x1_[0]; e[(I) & 3][3] = x1_[1];        \
-        }                                                                                                          \
-    }
-    // (P, P) of lane bank s -> every lane of the 16-lane row (bit mode: lane' = (lane & 0x13) | (s << 2))
-#define ZSWZ(S) { _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) sw[(S) & 1][ii] = (unsigned)__builtin_amdgcn_ds_swizzle((int)L[ii], 0x13 | (((S) << 2) << 5)); }
-#define VS(I)                                                                                                      \
-    {                                                                                                              \
-        if constexpr (MS == 64) {                                                                                  \
-            if (((I) & 3) == 0) {                                                                                  \
-                _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) { Az[0][ii] = sw[((I) >> 2) & 1][ii] & zmask0; Az[1][ii] = sw[((I) >> 2) & 1][ii] & zmask1; } \
-                if ((I) < 12) ZSWZ(((I) >> 2) + 1)                                                                 \
-            }                                                                                                      \
-        } else if (((I) & 1) == 0) {      /* M = 32: the A operand of the step's two tokens (pairs 2 h, 2 h + 1 of block s), for both tiles */ \
-            Az[0][0] = sw[((I) >> 2) & 1][(I) & 2] & d4mx; Az[0][1] = sw[((I) >> 2) & 1][(I) & 2] & d4my;          \
-            Az[0][2] = sw[((I) >> 2) & 1][((I) & 2) + 1] & d4mx; Az[0][3] = sw[((I) >> 2) & 1][((I) & 2) + 1] & d4my; \
-            if (((I) & 3) == 2 && (I) < 12) ZSWZ(((I) >> 2) + 1)                                                   \
-        }                                                                                                          \
-        constexpr int az_ = MS == 64 ? (((I) >> 1) & 1) : 0;                                                       \
-        O.t[(I) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8f16(Az[az_][0], Az[az_][1], Az[az_][2], Az[az_][3]), \
-                                                              as_v8f16(e[(I) & 3][0], e[(I) & 3][1], e[(I) & 3][2], e[(I) & 3][3]), \
-                                                              O.t[(I) & 1], 0, 0, 0);                              \
-        asm volatile("" : "+v"(O.t[(I) & 1]));                                                                     \
-    }
-    // ---- online softmax of the unit of round J whose scores are in D: lane (quad b, head j) holds tokens t_u + 4 b + i.  The
-    //      reference moves only when a raw score exceeds thr (SoftRef); the new one is the maximum over the head's 16 lanes ----
-#define SOFTMAX(J)                                                                                                 \
-    {                                                                                                              \
-        float x_[4];                                                                                               \
-        const int t_u = t0 + (J) * t_step;                                                                         \
-        if (t_u + 64 <= T) {                                                                                       \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) x_[i] = D[0][i] + D[1][i];                               \
-        } else {      /* the unit that holds token T - 1 (wave-uniform); a unit past it gives -inf everywhere */   \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) x_[i] = t_u + (lane & ~3) + i < T ? D[0][i] + D[1][i] : -INFINITY; \
-        }                                                                                                          \
-        const float mx_ = max3_raw(max3_raw(x_[0], x_[1], x_[2]), x_[3], x_[3]);                                   \
-        if (__any(mx_ > s_thr)) {                                                                                  \
-            float mq_ = mx_;                                                                                       \
-            mq_ = fmaxf(mq_, MILLION_DPP(mq_, 0x124));      /* row_ror:4 */                                        \
-            mq_ = fmaxf(mq_, MILLION_DPP(mq_, 0x128));      /* row_ror:8 */                                        \
-            const float m_new = fmaxf(s_m, rows_max(mq_) * c_);                                                    \
-            const float m_safe = m_new > -INFINITY ? m_new : 0.f;                                                  \
-            const float alpha = fast_exp2(s_m - m_safe);                                                           \
-            if (__any(m_new > s_m && s_m > -INFINITY)) rescale_acc(O, alpha, G, lane);                             \
-            s_l *= alpha;                                                                                          \
-            s_m = m_new;                                                                                           \
-            s_neg = (m_new > -INFINITY ? -m_new : 0.f) + idle;                                                     \
-            s_thr = (m_new + 8.0f) * inv_c;                                                                        \
-        }                                                                                                          \
-        float ps_ = 0.f;                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-            const float pr_ = fast_exp2(fmaf(x_[i], c_, s_neg));                                                   \
-            ps_ += pr_;                                                                                            \
-            const h2 pp_ = {(f16)pr_, (f16)pr_};                                                                   \
-            L[i] = __builtin_bit_cast(unsigned, pp_);                                                              \
-        }                                                                                                          \
-        s_l += ps_;                                                                                                \
-        ZSWZ(0)                                                                                                    \
-    }
-#define FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
-#define FOR32(X) FOR16(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
-    // (every step index is a literal: the MFMA's blgp field and the swizzle patterns are immediates)
-    // the scores of the unit in slot 0 alone (the prologue: nothing to interleave with, so the gathers run 6 k-steps ahead); the
-    // requests of round 1 go out in between - behind the barrier, one group every few k-steps (all eight right behind the barrier:
-    // the waves sat ~1 us in their load instructions while the CU's request queue was full)
-#define SA_STEP(SG)                                                                                                \
-    {                                                                                                              \
-        KM(SG)                                                                                                     \
-        if ((SG) + 6 < 32) KG(0, ((SG) + 6) & 31)                                                                  \
-        if ((SG) == 4) UNIT_REQ_K(1, 1)                                                                            \
-        if ((SG) == 12) UNIT_REQ_V(1, 1)                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-    }
-    // BLOCK: the 16 value steps of the unit in slot BL_SL (round bl_j) interleaved with the 32 score steps of the unit in the other
-    // slot (round bl_j + 1), whose first three gathers are in flight; the K bytes of round bl_j + 2 are requested at the start into
-    // slot BL_SL (its K bytes were used up by the previous block), its V bytes once the last value gather of round bl_j is out;
-    // the first three K gathers of round bl_j + 2 close the block
-#define BL_STEP(I)                                                                                                 \
-    {                                                                                                              \
-        VS(I)                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        VG(((I) + 2 < 16 ? BL_SL : BL_SLN), ((I) + 2) & 15)                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        KM(2 * (I))                                                                                                \
-        KG((2 * (I) + 3 < 32 ? BL_SLN : BL_SL), (2 * (I) + 3) & 31)                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        KM(2 * (I) + 1)                                                                                            \
-        KG((2 * (I) + 4 < 32 ? BL_SLN : BL_SL), (2 * (I) + 4) & 31)                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        if ((I) == 13) UNIT_REQ_V(BL_SL, bl_j + RING)                                                              \
-    }
-#define BLOCK() { UNIT_REQ_K(BL_SL, bl_j + RING) FOR16(BL_STEP) SOFTMAX(bl_j + 1) ++bl_j; }
-    // the value steps of the unit in slot VA_SL alone (gathers 0 and 1 are in flight; from here on 3 steps ahead)
-#define VA_STEP(I) { if ((I) + 3 < 16) VG(VA_SL, (I) + 3) VS(I) __builtin_amdgcn_sched_barrier(0); }
-    // A wave with n units runs: scores of unit 0 | n - 1 blocks (values of unit j beside the scores of unit j + 1) | values of unit
-    // n - 1.  Blocks alternate between the two ring slots (unit j lives in slot j & 1): one block, pairs in a loop, one more when n is odd.
-    const int nb = n_mine > 1 ? n_mine - 1 : 0;
-    TailReq treq;
-    treq.idx = 0; treq.gen = 0; treq.cen = 0; treq.base = 0; treq.done = false;
-    tail_mark_xcd(p, bh, split, wave, lane);      // this split's slot of the XCD census
-    int bl_j = 0;
-    {
-        KG(0, 0) KG(0, 1) KG(0, 2) KG(0, 3) KG(0, 4) KG(0, 5)
-        FOR32(SA_STEP)
-        SOFTMAX(0)      // (a wave without units: every score is masked to -inf, every probability 0)
-        STAMP(16);
-    }
-    if (n_mine > 0) {
-        VG(0, 0) VG(0, 1)
-        if (nb > 0) {
-            KG(1, 0) KG(1, 1) KG(1, 2)
-#define BL_SL 0
-#define BL_SLN 1
-            BLOCK()
-#undef BL_SL
-#undef BL_SLN
-            for (int w = 0; w < (nb - 1) >> 1; ++w) {
-#define BL_SL 1
-#define BL_SLN 0
-                BLOCK()
-#undef BL_SL
-#undef BL_SLN
-#define BL_SL 0
-#define BL_SLN 1
-                BLOCK()
-#undef BL_SL
-#undef BL_SLN
-                if (w == 0) STAMP(17);
-            }
-        }
-        tail_request(p, bh, p.nslots, wave, lane, treq);      // ~3 us ahead of the point where the tail needs the answers
-        STAMP(19);
-        if (n_mine & 1) {      // an odd number of units: the last one sits in slot 0 - behind one more block unless it is the only one
-            if (nb > 0) {
-#define BL_SL 1
-#define BL_SLN 0
-                BLOCK()
-#undef BL_SL
-#undef BL_SLN
-            }
-#define VA_SL 0
-            VG(0, 2)
-            FOR16(VA_STEP)
-#undef VA_SL
-        } else {
-#define VA_SL 1
-            VG(1, 2)
-            FOR16(VA_STEP)
-#undef VA_SL
-        }
-    }
-#undef BLOCK
-#undef BL_STEP
-#undef VA_STEP
-#undef SA_STEP
-#undef FOR32
-#undef FOR16
-#undef SOFTMAX
-#undef VS
-#undef ZSWZ
-#undef VG
-#undef KM
-#undef KG
-#undef LEAN_SIGMA
-#undef KBYTE4
-#undef KBYTE8
-#undef UNIT_REQ
-#undef UNIT_REQ_K
-#undef UNIT_REQ_V
-    STAMP(3);
-    // the tail wants head g's reference in lane g and row sums that rows_sum() completes: add up the head's four lanes of a row
-    float l_row = s_l;
-    l_row += MILLION_DPP(l_row, 0x124);
-    l_row += MILLION_DPP(l_row, 0x128);
-    merge_and_publish<(MS == 64 ? 640 : 320), false>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, s_m, l_row, treq);
-#undef STAMP
-}
+#include "attn_lean.h"      // attn_lean_kernel (round 5): the MFMA-lean core on this file's launch skeleton and tail
 
 // Self-check of the row-swap reductions (tests/test_gpu_parity.py): one wave, in[64] -> max / sum over the
 // four 16-lane rows per column.
@@ -2614,7 +2092,13 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // A split takes every nsplit-th window row and has kNW * kResRows = 128 slots for them in its waves' residual tiles:
 // windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
+// d = 64 with M = 32 / 16 (d_m = 2 / 4): the lean kernel only (round 5; before: the tile kernel) - 256 centroids, up to 4 query heads
+// per kv head
+static bool lean_d64_shape(const AttnParams &p) {
+    return p.d == 64 && (p.M == 32 || p.M == 16) && p.C == 256 && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
+}
 bool attn_mfma_shape_ok(const AttnParams &p) {
+    if (lean_d64_shape(p)) return true;
     if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head
         return (p.C == 256 || p.C == 128) && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
     return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxGMfma && p.rcap <= 4 * kNW * kResRows;
@@ -2675,12 +2159,19 @@ static int mfma_splits(const AttnParams &p) {
 static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T + ns * 256 - 1) / (ns * 256) <= 64; }
 
 // C = 128 runs on the streaming kernel only: without it (T = 0, more than 1M tokens) the call goes back to the caller
+// the lean kernel takes the call (launch_attn_mfma): pages of 64 / 128 tokens, streaming policy
+static bool lean_takes(const AttnParams &p) {
+    return attn_mfma_supported(p) && p.C == 256 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && g_mfma_policy == 0 &&
+           mfma_stream_ok(p, mfma_splits(p)) && (p.d == 64 || (p.M == 64 || (p.M == 32 && !(g_mfma_form & 1))));
+}
 bool attn_mfma_handles(const AttnParams &p) {
+    if (p.d == 64) return lean_takes(p);      // no other MFMA kernel of this file takes d = 64: the caller goes on to the tile kernel
     if (p.M == 16) return attn_mfma_supported(p) && g_mfma_policy == 0 && mfma_stream_ok(p, mfma_splits(p));      // streaming kernel or not at all
     return attn_mfma_supported(p) && (p.C != 128 || mfma_stream_ok(p, mfma_splits(p)));
 }
 // the call will run the STREAMING kernel (not the grouped fallback): million_attn_kernel_kind
 bool attn_mfma_streams(const AttnParams &p) {
+    if (p.d == 64) return lean_takes(p);
     return attn_mfma_supported(p) && g_mfma_policy == 0 && mfma_stream_ok(p, mfma_splits(p));
 }
 
@@ -2730,10 +2221,28 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
     const dim3 grid(ns, bh), block(kNW * 64);
+    if (p.d == 64) {       // lean kernel or nothing of this file (the caller's next choice: the tile kernel)
+        if (!lean_takes(p_in)) return kAttnNotHandled;
+        if (p.M == 32) {
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32, 64>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32, 64>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 32, 64>), grid, block, kLdsBytes, s, p);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 16, 64>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 16, 64>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 16, 64>), grid, block, kLdsBytes, s, p);
+        }
+    } else
     if (p.M == 16) {       // d_m = 8 form: the streaming kernel or the tile kernel (the caller's next choice)
         if (!stream_ok || g_mfma_policy != 0) return kAttnNotHandled;
         if (p.C == 128) hipLaunchKernelGGL((attn_stream_kernel<16, 2, 7>), grid, block, kLdsBytes, s, p);

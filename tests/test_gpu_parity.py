@@ -1512,12 +1512,16 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
     gold = oracle.decode_attn(**c)
     t = _dev(torch, c)
     if T:
-        # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4)
+        # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4); d = 64 with M = 32 /
+        # 16 (d_m = 2 / 4), 256 centroids and up to 4 heads per kv head the lean kernel (round 5) on pages of 64 / 128 tokens
         stream16 = d == 128 and M == 16 and nh // nhk <= 4
+        lean64 = d == 64 and M in (32, 16) and C == 256 and nh // nhk <= 4
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
-                     v_codes=t["v_codes"]) == (2 if stream16 else 4)
+                     v_codes=t["v_codes"]) == (2 if stream16 or lean64 else 4)
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
-                     page_size=64, n_pages_cap=(T + 63) // 64) == (1 if stream16 else 3)
+                     page_size=64, n_pages_cap=(T + 63) // 64) == (1 if stream16 or lean64 else 3)
+        assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
+                     page_size=32, n_pages_cap=(T + 31) // 32) == (1 if stream16 else 3)      # 32-token pages: never the lean kernel
     _check(_run_rowmajor(torch, ops, c, M, C), gold, "tile rowmajor")
     if T:
         for ps in (32, 64, 128):
