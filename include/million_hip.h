@@ -227,9 +227,10 @@ int million_pq_decode_attn_append(const million_attn_desc *desc, const void *q, 
 int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh_k, int n_tokens, int M,
                               int64_t v_stride_b, int64_t v_stride_h, million_stream_t stream);
 
-/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = streaming MFMA kernel (d = 128 with M in {64, 32}, and
+/* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = streaming MFMA kernels (d = 128 with M in {64, 32}, and
  * d = 128 / M = 16 with up to 4 query heads per kv head; any batch and any context up to 1M tokens per (b, kv head): calls with
- * more than 64 rounds per wave get more splits),
+ * more than 64 rounds per wave get more splits; with 256 centroids, up to 4 query heads per kv head and pages of 64 / 128 tokens
+ * the "lean" form of it runs - csrc/attn_lean.h - which also takes d = 64 with M in {32, 16}),
  * 2 = the same after transposing row-major V codes into workspace scratch (one extra launch), 3 = tile MFMA kernel
  * (d = 64 with M in {16, 32, 64}; d = 128 with M = 16 and more than 4 query heads per kv head), 4 = the same after the
  * transpose, 5 = the grouped MFMA kernel (the streaming kernel's fallback on its M = 64 / 32 shapes: no quantised token yet,
@@ -240,7 +241,8 @@ int million_attn_kernel_kind(const million_attn_desc *desc);
  * only (never the streaming one), 4 = auto, but the helper workgroups of the split merge give up at once (exercises the
  * last arriver's take-over path of the MFMA kernels' tail: every give-up bit is set before the launch's first ticket),
  * 8 = auto, but the helpers have no patience: each gives up through the real path (its atomic on the ticket word) unless
- * every workgroup has already taken its ticket. */
+ * every workgroup has already taken its ticket, 16 = auto, but the shapes of the lean kernel (csrc/attn_lean.h) stay on the
+ * streaming / tile kernels (A/B and the tests of those kernels' forms). */
 void million_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------
