@@ -242,7 +242,8 @@ int million_attn_kernel_kind(const million_attn_desc *desc);
  * last arriver's take-over path of the MFMA kernels' tail: every give-up bit is set before the launch's first ticket),
  * 8 = auto, but the helpers have no patience: each gives up through the real path (its atomic on the ticket word) unless
  * every workgroup has already taken its ticket, 16 = auto, but the shapes of the lean kernel (csrc/attn_lean.h) stay on the
- * streaming / tile kernels (A/B and the tests of those kernels' forms). */
+ * streaming / tile kernels (A/B and the tests of those kernels' forms), 64 = auto, but million_prefill_attn runs its plain
+ * tile loop at d = 128 instead of the pipelined one (csrc/prefill.hip; A/B and the tests of both forms). */
 void million_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------

@@ -59,23 +59,33 @@ struct LeanUnit { v4u k[NQ], v[NQ]; };
 // (DD / 4) q4 + 8 s .. in product s < DD / 32).  Values:
 //   d_m = 2 (z-rows): v[2 pi + z][i] = dims (2 m, 2 m + 1), m = 32 pi + 16 z + n, of tile row 4 kg + i: the B operand of product (pi, z)
 //   d_m = 4: v[2 j + s_][2 rr .. + 1] = dims 4 (n + 16 j) .. + 3 of tile row 4 kg + 2 s_ + rr: the B operand of product (tile j, k-step s_)
-template <int DD>
+//   d_m = 1 (DR = 64 rows computed as d_m = 2 with every odd dim zero, DD = 128): v[x][i] = (dim 16 x + n, 0) of tile row 4 kg + i
+template <int DD, int DR = DD>
 struct LeanResTile {
-    v4u k[DD / 32];
+    v4u k[DR / 32];
     unsigned v[DD / 32][4];
 };
-template <int DD, bool DM2>
+template <int DD, bool DM2, int DR = DD>
 __device__ __forceinline__ void lean_load_res_tile(const AttnParams &p, int bh, const f16 *kr, const f16 *vr, int wave, int rcnt,
-                                                   int split, int rstart, int r_old, int lane, LeanResTile<DD> &t) {
+                                                   int split, int rstart, int r_old, int lane, LeanResTile<DD, DR> &t) {
     const int q4 = lane >> 4, c16 = lane & 15;
     {
         bool is_new;
-        const long long off = (res_row_off(p, kResRows * wave + c16, wave, rcnt, split, rstart, r_old, is_new) >> 7) * DD;
-        const f16 *kp = (is_new ? p.k_new + (long long)bh * DD : kr + off) + (DD / 4) * q4;
+        const long long off = (res_row_off(p, kResRows * wave + c16, wave, rcnt, split, rstart, r_old, is_new) >> 7) * DR;
+        const f16 *kp = (is_new ? p.k_new + (long long)bh * DR : kr + off) + (DR / 4) * q4;
 #pragma unroll
-        for (int s = 0; s < DD / 32; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
+        for (int s = 0; s < DR / 32; ++s) t.k[s] = *(const v4u *)(kp + 8 * s);
     }
-    if constexpr (DM2) {
+    if constexpr (DR != DD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool is_new;
+            const long long off = (res_row_off(p, kResRows * wave + 4 * q4 + i, wave, rcnt, split, rstart, r_old, is_new) >> 7) * DR;
+            const unsigned short *vp = (const unsigned short *)(is_new ? p.v_new + (long long)bh * DR : vr + off) + c16;
+#pragma unroll
+            for (int x = 0; x < DD / 32; ++x) t.v[x][i] = vp[16 * x];
+        }
+    } else if constexpr (DM2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bool is_new;
@@ -103,16 +113,23 @@ __device__ __forceinline__ void lean_load_res_tile(const AttnParams &p, int bh, 
 }
 
 // MS = M (subspaces), DD = d.  d_m = DD / MS is 2 (z-row values) or 4 (dim-position values).
-template <int MODE, int MS = 64, int DD = 128>
+// DR = 64 with DD = 128, MS = 64 is the d_m = 1 shape (d = 64, M = 64) run as d_m = 2 with every odd dim ZERO: the 2-byte codebook
+// entries are widened to (value, 0) words while they are copied to LDS (the same 64 + 64 KiB as d = 128 / M = 64), the query words
+// are (q, 0), the residual rows are read at their real length, and the accumulators - whose odd-parity rows stay zero - are
+// packed into the d = 64 layout by 8 ds_bpermute in front of the tail.  Same gathers and products per token as d = 128 / M = 64
+// (half of the score MACs multiply zeros: the matrix pipe is not what bounds this kernel).
+template <int MODE, int MS = 64, int DD = 128, int DR = DD>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     static_assert((DD == 128 && (MS == 64 || MS == 32)) || (DD == 64 && (MS == 32 || MS == 16)), "lean kernel: d_m = 2 or 4 at d = 128 / 64");
+    static_assert(DR == DD || (DR == 64 && DD == 128 && MS == 64), "lean kernel: the padded form is d = 64 / M = 64 only");
+    constexpr bool PAD = DR != DD;
     constexpr bool DM2 = DD / MS == 2;
     constexpr int kLog2M = MS == 64 ? 6 : MS == 32 ? 5 : 4;
     constexpr int NK = DD / 4;                       // score k-steps (4 dims each) per unit
     constexpr int NQ = MS / 16;                      // 16-byte requests per unit and side
     constexpr int NPI = DD / 64;                     // value accumulators: d_m = 2: pairs pi of 32 subspaces; d_m = 4: column tiles of 16 subspaces
     constexpr int NV = 8 * NPI;                      // value products per unit: (token step s) x (phase phi | token pair h) x (pi | tile)
-    constexpr int NT = DD / 16;                      // 16-byte pieces of a codebook image per thread (64 KiB at d = 128, 32 at d = 64)
+    constexpr int NT = DR / 16;                      // 16-byte pieces of a codebook image per thread (64 KiB at d = 128, 32 at d = 64)
     constexpr int MSTAG = DM2 ? 640 : 320;           // accumulator layout for the tail (merge_and_publish)
     constexpr int RING = 2;      // ring slots of one 64-token unit (8 NQ registers each).  Three slots (the K bytes two blocks ahead
                                  // instead of one) were measured and are slower at every shape: 24.98 vs 22.65 us at two requests,
@@ -167,20 +184,26 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     // A lane's pairs 2 v, 2 v + 1 are ONE 16-byte load (dims 32 v + 8 kg .. + 7), so k-step (u, lambda) covers the 4-dim group
     // sigma = 8 (u >> 1) + 2 lambda + (u & 1) (LEAN_SIGMA below; d_m = 2: subspaces 2 sigma, 2 sigma + 1; d_m = 4: subspace sigma):
     // any order of the groups will do
-    const f16 *qrow = p.q + ((long long)b * p.nh + head0(p, hk)) * DD;
+    const f16 *qrow = p.q + ((long long)b * p.nh + head0(p, hk)) * DR;
     v2u Q[NK / 4];
 #pragma unroll
     for (int v = 0; v < DD / 32; ++v) {
-        v4u t = *(const v4u *)(qrow + (hj < G ? hj : 0) * DD + 32 * v + 8 * kg);
+        v4u t;
+        if constexpr (PAD) {      // padded dims 32 v + 8 kg .. + 7 = real dims 16 v + 4 kg .. + 3, each widened to (q, 0)
+            const v2u t2 = *(const v2u *)(qrow + (hj < G ? hj : 0) * DR + 16 * v + 4 * kg);
+            t = v4u{t2[0] & 0xffffu, t2[0] >> 16, t2[1] & 0xffffu, t2[1] >> 16};
+        } else {
+            t = *(const v4u *)(qrow + (hj < G ? hj : 0) * DD + 32 * v + 8 * kg);
+        }
         if (hj >= G) t = v4u{0, 0, 0, 0};
         Q[2 * v] = v2u{t[0], t[1]};
         Q[2 * v + 1] = v2u{t[2], t[3]};
     }
     const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
     h2 new_k = {}, new_v = {};
-    if (append_wave && 2 * lane < DD) {
-        new_k = *(const h2 *)(p.k_new + (long long)bh * DD + 2 * lane);
-        new_v = *(const h2 *)(p.v_new + (long long)bh * DD + 2 * lane);
+    if (append_wave && 2 * lane < DR) {
+        new_k = *(const h2 *)(p.k_new + (long long)bh * DR + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bh * DR + 2 * lane);
     }
     v4u tabk[NT], tabv[NT];
     const int rot = (blockIdx.x + 5 * blockIdx.y) & (NT - 1);
@@ -208,15 +231,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     const bool has_res = kResRows * wave < rcnt;
     const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
     const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
-    LeanResTile<DD> rt;
-    v8f16 qb[DD / 32];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims (DD / 4) q4 + 8 s ..;
+    LeanResTile<DD, DR> rt;
+    v8f16 qb[DR / 32];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims (DD / 4) q4 + 8 s ..;
                             // d_m = 4: head c16 & 3 - the four column groups carry copies of the heads, as in the streaming kernel's form)
     if (has_res) {
-        lean_load_res_tile<DD, DM2>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+        lean_load_res_tile<DD, DM2, DR>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
         const int hq = DM2 ? n16 : hj;
-        const f16 *qv = qrow + (hq < G ? hq : 0) * DD + (DD / 4) * kg;
+        const f16 *qv = qrow + (hq < G ? hq : 0) * DR + (DR / 4) * kg;
 #pragma unroll
-        for (int s = 0; s < DD / 32; ++s) {
+        for (int s = 0; s < DR / 32; ++s) {
             v4u t = *(const v4u *)(qv + 8 * s);
             if (hq >= G) t = v4u{0, 0, 0, 0};
             qb[s] = __builtin_bit_cast(v8f16, t);
@@ -263,6 +286,16 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     {
         v4u *ld = (v4u *)smem;
         v4u *ldv = (v4u *)(smem + kVBase);
+        if constexpr (PAD) {      // 2-byte entries -> (value, 0) words: piece pi of an image becomes pieces 2 pi, 2 pi + 1 of its LDS copy
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const unsigned pi_ = ((i + rot) & (NT - 1)) * (kNW * 64) + tid;
+                ld[2 * pi_] = v4u{tabk[i][0] & 0xffffu, tabk[i][0] >> 16, tabk[i][1] & 0xffffu, tabk[i][1] >> 16};
+                ld[2 * pi_ + 1] = v4u{tabk[i][2] & 0xffffu, tabk[i][2] >> 16, tabk[i][3] & 0xffffu, tabk[i][3] >> 16};
+                ldv[2 * pi_] = v4u{tabv[i][0] & 0xffffu, tabv[i][0] >> 16, tabv[i][1] & 0xffffu, tabv[i][1] >> 16};
+                ldv[2 * pi_ + 1] = v4u{tabv[i][2] & 0xffffu, tabv[i][2] >> 16, tabv[i][3] & 0xffffu, tabv[i][3] >> 16};
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NT; ++i) ld[((i + rot) & (NT - 1)) * (kNW * 64) + tid] = tabk[i];
 #pragma unroll
@@ -271,6 +304,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
             if constexpr (DD == 128) ldv[pi_] = tabv[i];
             else      // d = 64: a code's row is 128 bytes; in LDS it sits at c * 256, so that a code byte is byte 1 of its row's address
                 *(v4u *)(smem + kVBase + (((pi_ * 16u) >> 7) << 8) + ((pi_ * 16u) & 127u)) = tabv[i];
+        }
         }
     }
     STAMP(8);
@@ -281,10 +315,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     Acc8 O;
     O.t[0] = v4f32{0.f, 0.f, 0.f, 0.f};
     O.t[1] = v4f32{0.f, 0.f, 0.f, 0.f};
-    if (append_wave && 2 * lane < DD) {
+    if (append_wave && 2 * lane < DR) {
         int row_n = rstart + r_old;
         row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
-        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * DD + 2 * lane;
+        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * DR + 2 * lane;
         *(h2 *)(p.k_res_w + o) = new_k;
         *(h2 *)(p.v_res_w + o) = new_v;
     }
@@ -307,7 +341,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         {
             v4f32 Dr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < DD / 32; ++s) Dr = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, rt.k[s]), qb[s], Dr, 0, 0, 0);
+            for (int s = 0; s < DR / 32; ++s) Dr = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, rt.k[s]), qb[s], Dr, 0, 0, 0);
 #pragma unroll
             for (int rho = 0; rho < 4; ++rho) scr[rho] = (kResRows * wave + 4 * kg + rho) < rcnt ? Dr[rho] * p.scale_log2e : -INFINITY;
         }
@@ -580,7 +614,20 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     float l_row = s_l;
     l_row += MILLION_DPP(l_row, 0x124);
     l_row += MILLION_DPP(l_row, 0x128);
-    merge_and_publish<MSTAG, false, DD>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, s_m, l_row, treq);
+    if constexpr (PAD) {
+        // padded accumulators: O.t[j'][g], lane (rg', n'), rg' even: real dim 32 j' + 16 (rg' >> 1) + n' (odd rg': the zero dims).
+        // The d = 64 layout wants lane (rg, n) of t[0] to hold dim D = 32 (rg >> 1) + 2 n + (rg & 1): j' = rg >> 1,
+        // lane' = 32 (n >> 3) + 2 (n & 7) + (rg & 1)
+        const int src = (32 * (n16 >> 3) + 2 * (n16 & 7) + (kg & 1)) << 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int v0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, O.t[0][g]));
+            const int v1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, O.t[1][g]));
+            O.t[0][g] = __builtin_bit_cast(float, (kg >> 1) ? v1 : v0);
+            O.t[1][g] = 0.f;
+        }
+    }
+    merge_and_publish<MSTAG, false, DR>(p, smem, b, hk, split, G, tid, lane, wave, dbg_on, O, s_m, l_row, treq);
 #undef STAMP
 }
 

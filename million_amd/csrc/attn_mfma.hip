@@ -2092,10 +2092,10 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // A split takes every nsplit-th window row and has kNW * kResRows = 128 slots for them in its waves' residual tiles:
 // windows of up to 128 rows work with any split count, longer ones (extended_residual_size 256, the reference's
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
-// d = 64 with M = 32 / 16 (d_m = 2 / 4): the lean kernel only (round 5; before: the tile kernel) - 256 centroids, up to 4 query heads
-// per kv head
+// d = 64 with M = 32 / 16 (d_m = 2 / 4) and M = 64 (d_m = 1: run as d_m = 2 with every odd dim zero, attn_lean.h): the lean kernel
+// only (round 5; before: the tile kernel) - 256 centroids, up to 4 query heads per kv head
 static bool lean_d64_shape(const AttnParams &p) {
-    return p.d == 64 && (p.M == 32 || p.M == 16) && p.C == 256 && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
+    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && p.C == 256 && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
 }
 bool attn_mfma_shape_ok(const AttnParams &p) {
     if (lean_d64_shape(p)) return true;
@@ -2227,13 +2227,20 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 64, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 64, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 64, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
     const dim3 grid(ns, bh), block(kNW * 64);
     if (p.d == 64) {       // lean kernel or nothing of this file (the caller's next choice: the tile kernel)
         if (!lean_takes(p_in)) return kAttnNotHandled;
-        if (p.M == 32) {
+        if (p.M == 64) {
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 64, 128, 64>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 64, 128, 64>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 64, 128, 64>), grid, block, kLdsBytes, s, p);
+        } else if (p.M == 32) {
             if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32, 64>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32, 64>), grid, block, kLdsBytes, s, p);
             else hipLaunchKernelGGL((attn_lean_kernel<2, 32, 64>), grid, block, kLdsBytes, s, p);

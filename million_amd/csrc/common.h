@@ -420,6 +420,7 @@ int device_cus();
 bool device_once(int family);      // true exactly once per (current device, family 0..7)
 
 int read_tail_faults();             // attn_mfma.hip: merges that ran out of their poll bound since the last call (and clears)
+void set_prefill_policy(int plain);  // prefill.hip: million_set_force_generic(64) = the plain form of the prompt-attention kernel at d = 128 (A/B, tests)
 void set_mfma_policy(int policy);   // attn_mfma.hip: A/B and test knob behind million_set_force_generic(2 / 4 / 8): bit 0 = grouped kernel only, bits 2:1 = merge-helper test mode
 
 }  // namespace million

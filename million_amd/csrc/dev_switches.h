@@ -13,6 +13,7 @@
 //                        xor-ed into a sink instead of gathered, multiplied and soft-maxed         profiles/r04_launch_floor.txt
 //     prefill.hip     1  no exponentials, 2 no tile barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
 //                                                                                                 profiles/r03_prefill.txt, r04_prefill.txt
+//                   256  pipelined kernel: no exponentials, 512 no tile DMA behind the prologue, 1024 no tile wait/barrier  profiles/r05_prefill.txt
 //   MILLION_TILE_PROF      attn_tile.hip: per-tile shader-clock stamps (tools/tile_prof.py)
 //   MILLION_DEV_M32_PACKED() run-time A/B (environment MILLION_M32_PACKED=1, dev builds only): M = 32 keeps the packed value form
 //                          at up to 4 query heads per kv head too (the product build takes the d_m = 4 form there and the

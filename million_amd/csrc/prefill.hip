@@ -298,13 +298,272 @@ __global__ __launch_bounds__(kPW * 64, 2) void prefill_attn_kernel(PrefillParams
     }
 }
 
+// =====================================================================================================
+// Pipelined form (round 5; d = 128, 8 waves): the same tiles, layouts and numerics as prefill_attn_kernel above, but a wave's
+// instruction stream is software-pipelined across 32-key HALF tiles and every matrix instruction is PINNED where it is written:
+//   half-step h:   phase 1   the 8 score products of half h + 1 (K operands requested three steps ahead), each followed by the
+//                            exponentials / row sums / fp16 pack of TWO scores of half h; its last three gaps request phase 2's
+//                            first three V operands;
+//                  phase 2   the 8 value products of half h (V operands three steps ahead), each followed by one v_max3 of the running maximum over half h + 1's
+//                            raw scores; then the reference decision for half h + 1 (lazy reference as in the decode kernels: it
+//                            moves - rescale of O and l, a wave-uniform branch - only when a score exceeds it by 2^8: P <= 2^8 is an
+//                            exact fp16 operand; the rescale sits behind ALL value products of half h, cdna_hip_programming.md T13).
+// Whole-tile pipelining (16 + 16 products per phase) holds both score halves of two tiles, 16 probability pairs and their operands:
+// 256 registers and 41-127 spilled dwords - qf and the fragment addresses reloaded in front of every product with vmcnt(0) waits
+// that also wait for the tile DMA: 646 TFLOP/s against 979 for the plain kernel.  Half tiles keep 16 + 16 score registers.
+// The K stream runs half a tile ahead of V: iteration t reads K halves 2 t + 1, 2 t + 2 and V tile t, and its DMA brings K halves
+// 2 t + 3, 2 t + 4 and V tile t + 1 (K half h sits in quarter h & 3 of the K region = tile (h >> 1) & 1's buffer: nothing moves).
+// Round 4 built a cross-tile pipeline at source level and measured no gain: hipcc kept 'ds_read, s_waitcnt, v_mfma' triples and runs
+// of 30-100 vector instructions - an MFMA is register-only and has no chain to sched_barrier() in the selection DAG, so the compiler
+// moves it at will (seen again in the lean decode kernel this round).  Here an empty asm volatile("" : "+v"(accumulator)) behind
+// every product and behind every softmax slice fixes the order: M, 7 vector, M, 7 vector ... as written.
+// =====================================================================================================
+#define PF_PIN(x) asm volatile("" : "+v"(x))
+__global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillParams p) {
+    constexpr int D = 128, kPW = 8, DS = D / 16, NB = D / 32, kTileBytes = kKV * 2 * D;
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_smem != 0u) __builtin_trap();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    int id = blockIdx.x;
+    const int hk = id % p.nh_k;
+    id /= p.nh_k;
+    const int n_hg = p.G / p.hpw;
+    const int hg = id % n_hg;
+    id /= n_hg;
+    const int qb = p.n_qb - 1 - id % p.n_qb;
+    const int b = id / p.n_qb;
+    const int wph = kPW / p.hpw;
+    const int QB = wph * 32;
+    const int g = hg * p.hpw + wave / wph;
+    const int head = hk * p.G + g;
+    const int q_lo = qb * QB + (wave % wph) * 32;
+    const int q_row = q_lo + r32;
+    const int q_pos = p.q_pos0 + q_row;
+    v8h qf[DS];
+    {
+        const int qr = q_row < p.n_q ? q_row : p.n_q - 1;
+        const f16 *qp = p.q + b * p.q_sb + head * p.q_sh + (long long)qr * p.q_sn + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) qf[s] = *(const v8h *)(qp + 16 * s);
+    }
+    const int wg_q_hi = qb * QB + QB - 1 < p.n_q - 1 ? qb * QB + QB - 1 : p.n_q - 1;
+    int kv_end_wg = p.causal ? p.q_pos0 + wg_q_hi + 1 : p.n_kv;
+    kv_end_wg = kv_end_wg < p.n_kv ? kv_end_wg : p.n_kv;
+    const int nt = kv_end_wg > 0 ? (kv_end_wg + kKV - 1) / kKV : 0;
+    const int nh2 = 2 * nt;                                              // 32-key halves of this workgroup
+    const int w_pos_lo = p.q_pos0 + q_lo, w_pos_hi = p.q_pos0 + q_lo + 31;
+    const bool wave_live = q_lo < p.n_q;
+    const f16 *kbase = p.k + b * p.k_sb + hk * p.k_sh;
+    const f16 *vbase = p.v + b * p.v_sb + hk * p.v_sh;
+    // one-KiB pieces (4 rows of a tile): a K half = pieces 8 jt .. 8 jt + 7 of its tile: one per wave; a V tile = 16: two per wave
+    int prow[2], pch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pos = 64 * (wave + kPW * i) + lane;
+        prow[i] = pos >> 4;
+        pch[i] = (pos & 15) ^ (((prow[i] & 3) << 2) | ((prow[i] >> 2) & 3));
+    }
+    auto dma_piece = [&](int t, int i, bool is_v) {      // piece wave + 8 i of tile t's K or V side -> buffer t & 1
+        int kvr = t * kKV + prow[i];
+        kvr = kvr < p.n_kv ? kvr : p.n_kv - 1;
+        const f16 *src = (is_v ? vbase + (long long)kvr * p.v_sn : kbase + (long long)kvr * p.k_sn) + 8 * pch[i];
+        const unsigned dst = 2u * kTileBytes * (t & 1) + (is_v ? kTileBytes : 0) + 1024u * (wave + kPW * i);
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+    };
+    auto dma_k_half = [&](int h) { if (h < nh2) dma_piece(h >> 1, h & 1, false); };
+    auto dma_v_tile = [&](int t) { if (t < nt) { dma_piece(t, 0, true); dma_piece(t, 1, true); } };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    v16f O[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[i][j] = 0.f;
+    const float c = p.scale_log2e, inv_c = 1.0f / p.scale_log2e;
+    float m_ref = -INFINITY, neg_ref = 0.f, thr_raw = -INFINITY, l_run = 0.f;
+    const int qd = (lane >> 2) & 3, pp = lane & 3, g16 = (lane >> 4) & 1;
+
+    // wave-uniform predicates of half h (keys 32 h .. 32 h + 31) for this wave
+    auto live = [&](int h) { return h < nh2 && wave_live && (!p.causal || 32 * h <= w_pos_hi); };
+    auto masked = [&](int h) { return (p.causal && 32 * h + 31 > w_pos_lo) || 32 * h + 32 > p.n_kv; };
+    // raw scores of half h -> -inf where the row does not attend; compares against immediates: key = 32 h + 4 hh + (j & 3) + 8 (j >> 2) <= lim
+    auto mask_half = [&](int h, v16f &S) {
+        const int lim = p.causal ? (q_pos < p.n_kv - 1 ? q_pos : p.n_kv - 1) : p.n_kv - 1;
+        const int rel = lim - 32 * h - 4 * hh;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) S[j] = (j & 3) + 8 * (j >> 2) <= rel ? S[j] : -INFINITY;
+    };
+    // the reference decision for a half whose raw per-lane maximum is mx (both half-waves hold the same query rows)
+    auto decide = [&](float mx) {
+        {
+            const v2u ex = swap32_self(__float_as_uint(mx));
+            const unsigned e0 = ex[0], e1 = ex[1];
+            mx = fmaxf(__uint_as_float(e0), __uint_as_float(e1));
+        }
+        if (__any(mx > thr_raw)) {
+            const float m_new = fmaxf(m_ref, mx * c);
+            const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(m_ref - m_safe);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)      // alpha = 0 on the first move (O = 0 then), 1 when only another row's maximum moved
+#pragma unroll
+                for (int j = 0; j < 16; ++j) O[i][j] *= alpha;
+            l_run *= alpha;
+            m_ref = m_new;
+            neg_ref = -m_safe;
+            thr_raw = (m_new + 8.0f) * inv_c;
+        }
+    };
+    // Fragment addresses as 8 + 8 lane constants with everything else in the ds_read immediates (the plain kernel keeps 16 + 32
+    // address registers live across its loop; the pipeline has no room for them).  pf_off(row, ch) = 256 row + 16 (ch ^ X(row)) with
+    // X = ((row & 3) << 2) | ((row >> 2) & 3):
+    //   K rows 32 jt + r32, chunk 2 s + hh: X depends on r32 only, so  addr = ka[s] + 256 * 32 jt,  ka[s] = 256 r32 + 16 ((2 s + hh) ^ X(r32))
+    //   V rows 32 jt + 16 ks + 8 hi + 4 hh + qd, chunk 4 blk + 2 g16 + (pp >> 1): row & 3 = qd, (row >> 2) & 3 = 2 hi + hh, so
+    //   addr = va[hi][blk] + 256 (32 jt + 16 ks),  va[hi][blk] = 256 (8 hi + 4 hh + qd) + 16 (((blk ^ qd) << 2) | ((2 g16 + (pp >> 1)) ^ (2 hi + hh))) + 8 (pp & 1)
+    unsigned ka[DS], va[2][NB];
+    {
+        const unsigned X = ((r32 & 3) << 2) | ((r32 >> 2) & 3);
+#pragma unroll
+        for (int s_ = 0; s_ < DS; ++s_) ka[s_] = 256u * r32 + 16u * ((2u * s_ + hh) ^ X);
+#pragma unroll
+        for (int hi_ = 0; hi_ < 2; ++hi_)
+#pragma unroll
+            for (int blk_ = 0; blk_ < NB; ++blk_)
+                va[hi_][blk_] = 256u * (8 * hi_ + 4 * hh + qd) + 16u * ((((unsigned)blk_ ^ qd) << 2) | ((2u * g16 + (pp >> 1)) ^ (2u * hi_ + hh))) + 8u * (pp & 1);
+    }
+    // K half HQ (0..3: buffer HQ >> 1, rows 32 (HQ & 1) ..), k-step S;  V of buffer BUFV, half JT, key step KS, operand half HI, dim block BLK
+#define PF_KFRAG(HQ, S) __builtin_bit_cast(v8h, ((lds_v4u_p)(size_t)ka[S])[(2u * kTileBytes * ((HQ) >> 1) + 256u * 32u * ((HQ) & 1)) / 16])
+#define PF_VFRAG(BUFV, JT, KS, HI, BLK) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)va[HI][BLK] + (2u * kTileBytes * (BUFV) + kTileBytes + 256u * (32u * (JT) + 16u * (KS))) / 8)
+
+    // prologue: K halves 0, 1, 2 and V tile 0
+    dma_k_half(0); dma_k_half(1); dma_k_half(2); dma_v_tile(0);
+#pragma unroll
+    for (int s = 0; s < DS; ++s) asm volatile("" : "+v"(qf[s]));      // hipcc's vmcnt model: Q has landed here, not 'somewhere in the loop'
+    dma_wait();
+    __syncthreads();
+    v16f SA, SB;      // raw scores: of the current half / accumulating the next one (roles swap every half-step)
+    bool cur_live = live(0);
+    if (cur_live) {      // scores of half 0 (plain), mask, reference
+#pragma unroll
+        for (int s = 0; s < DS; ++s)
+            SA = s == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(PF_KFRAG(0, s), qf[s], v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_32x32x16_f16(PF_KFRAG(0, s), qf[s], SA, 0, 0, 0);
+        if (masked(0)) mask_half(0, SA);
+        float mx = SA[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, SA[j]);
+        decide(mx);
+    }
+    // One half-step: half h (scores in C, reference decided; its V rows: buffer HQ >> 1, half HQ & 1) and half h + 1 (scores into N;
+    // its K rows: quarter (HQ + 1) & 3).  HQ = h & 3 is a compile-time constant: the tile loop is unrolled by two.
+    auto half_step = [&](auto hqc, v16f &C, v16f &N, const int h) {
+        constexpr int HQ = decltype(hqc)::value, HN = (HQ + 1) & 3, BUFV = HQ >> 1, JT = HQ & 1;
+        const bool nxt_live = live(h + 1);
+        if (cur_live) {      // a wave's last live half runs the same code: the scores of the half behind it are masked whole
+            float ls = 0.f, mx = -INFINITY;
+            unsigned pw8[8];
+            // phase 1: score products of half h + 1 (operands three k-steps ahead) | exponentials of half h; its last three gaps
+            // also request the first three value operands of phase 2
+            v8h af[3] = {PF_KFRAG(HN, 0), PF_KFRAG(HN, 1), PF_KFRAG(HN, 2)};
+            pv4s lo[3], hi[3];
+#pragma unroll
+            for (int s = 0; s < DS; ++s) {
+                if (s == 0) N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], N, 0, 0, 0);
+                PF_PIN(N);
+                if (s + 3 < DS) af[s % 3] = PF_KFRAG(HN, (s + 3) & 7);
+                else { lo[s - 5] = PF_VFRAG(BUFV, JT, 0, 0, (s - 5) & 3); hi[s - 5] = PF_VFRAG(BUFV, JT, 0, 1, (s - 5) & 3); }
+#if MILLION_EXP & 256
+                const float p0 = fmaf(C[2 * s], c, neg_ref), p1 = fmaf(C[2 * s + 1], c, neg_ref);
+#else
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(C[2 * s], c, neg_ref)), p1 = __builtin_amdgcn_exp2f(fmaf(C[2 * s + 1], c, neg_ref));
+#endif
+                ls += p0;
+                ls += p1;
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                const h2v t2 = {(f16)p0, (f16)p1};
+                pw8[s] = __builtin_bit_cast(unsigned, t2);
+                asm volatile("" : "+v"(pw8[s]), "+v"(ls));
+            }
+            if (!nxt_live || masked(h + 1)) mask_half(h + 1, N);
+            // phase 2: value products of half h (operands three steps ahead) | running maximum of half h + 1's raw scores
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ks = i >> 2, blk = i & 3;
+                typedef short v8s __attribute__((ext_vector_type(8)));
+                const v8s av = {lo[i % 3][0], lo[i % 3][1], lo[i % 3][2], lo[i % 3][3], hi[i % 3][0], hi[i % 3][1], hi[i % 3][2], hi[i % 3][3]};
+                const pv4u pwv = {pw8[4 * ks], pw8[4 * ks + 1], pw8[4 * ks + 2], pw8[4 * ks + 3]};
+                O[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, av), __builtin_bit_cast(v8h, pwv), O[blk], 0, 0, 0);
+                PF_PIN(O[blk]);
+                if (i + 3 < 8) { lo[i % 3] = PF_VFRAG(BUFV, JT, ((i + 3) >> 2) & 1, 0, (i + 3) & 3); hi[i % 3] = PF_VFRAG(BUFV, JT, ((i + 3) >> 2) & 1, 1, (i + 3) & 3); }
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(N[2 * i]), "v"(N[2 * i + 1]));
+                PF_PIN(mx);
+            }
+            l_run += ls;
+            decide(mx);
+        }
+        cur_live = nxt_live;
+    };
+    // iteration t: half-steps 2 t and 2 t + 1; its DMA: K halves 2 t + 3, 2 t + 4 (quarters last read in iteration t - 1) and V tile t + 1
+#if MILLION_EXP & 512
+#define PF_DMA(T) (void)0
+#else
+#define PF_DMA(T) dma_k_half(2 * (T) + 3); dma_k_half(2 * (T) + 4); dma_v_tile((T) + 1)
+#endif
+#if MILLION_EXP & 1024
+#define PF_SYNC() (void)0
+#else
+#define PF_SYNC() dma_wait(); __syncthreads()
+#endif
+    for (int t = 0; t < nt; t += 2) {
+        PF_DMA(t);
+        half_step(std::integral_constant<int, 0>{}, SA, SB, 2 * t);
+        half_step(std::integral_constant<int, 1>{}, SB, SA, 2 * t + 1);
+        PF_SYNC();
+        if (t + 1 < nt) {
+            PF_DMA(t + 1);
+            half_step(std::integral_constant<int, 2>{}, SA, SB, 2 * t + 2);
+            half_step(std::integral_constant<int, 3>{}, SB, SA, 2 * t + 3);
+            PF_SYNC();
+        }
+    }
+#undef PF_DMA
+#undef PF_SYNC
+#undef PF_KFRAG
+#undef PF_VFRAG
+    {
+        const v2u ex = swap32_self(__float_as_uint(l_run));
+        const unsigned e0 = ex[0], e1 = ex[1];
+        l_run = __uint_as_float(e0) + __uint_as_float(e1);
+    }
+    if (wave_live && q_row < p.n_q) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        f16 *op = p.out + b * p.o_sb + head * p.o_sh + (long long)q_row * p.o_sn + 4 * hh;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                typedef f16 h4 __attribute__((ext_vector_type(4)));
+                const h4 o = {(f16)(O[blk][4 * i] * inv), (f16)(O[blk][4 * i + 1] * inv), (f16)(O[blk][4 * i + 2] * inv),
+                              (f16)(O[blk][4 * i + 3] * inv)};
+                *(h4 *)(op + 32 * blk + 8 * i) = o;
+            }
+    }
+}
+#undef PF_PIN
+
 template <int D, int PW>
 static void launch_prefill_t(const PrefillParams &p, long long blocks, int lds, hipStream_t s) {
     hipLaunchKernelGGL((prefill_attn_kernel<D, PW>), dim3((unsigned)blocks), dim3(PW * 64), lds, s, p);
 }
 // dynamic-LDS attribute of the four instances: once per device, under the library's per-device mutex (common.h: device_once)
+static int g_prefill_plain = 0;      // A/B and tests (million_set_force_generic(64)): the plain (round-3) form at d = 128 too
+void set_prefill_policy(int plain) { g_prefill_plain = plain; }
 static void prefill_attrs_once() {
     if (!device_once(3)) return;
+    (void)hipFuncSetAttribute((const void *)prefill_attn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 128);
     (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 128);
     (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 128);
     (void)hipFuncSetAttribute((const void *)prefill_attn_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 64);
@@ -325,7 +584,8 @@ int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
     if (blocks > 0x7fffffffLL) { set_error("prefill: %lld workgroups", blocks); return MILLION_ERR_SHAPE; }
     const int lds = 4 * kKV * 2 * p.d;      // two buffers of (K tile, V tile)
     prefill_attrs_once();
-    if (p.d == 128) { if (pw == 4) launch_prefill_t<128, 4>(p, blocks, lds, s); else launch_prefill_t<128, 8>(p, blocks, lds, s); }
+    if (p.d == 128 && pw == 8 && !g_prefill_plain) hipLaunchKernelGGL(prefill_attn_pipe_kernel, dim3((unsigned)blocks), dim3(8 * 64), lds, s, p);
+    else if (p.d == 128) { if (pw == 4) launch_prefill_t<128, 4>(p, blocks, lds, s); else launch_prefill_t<128, 8>(p, blocks, lds, s); }
     else { if (pw == 4) launch_prefill_t<64, 4>(p, blocks, lds, s); else launch_prefill_t<64, 8>(p, blocks, lds, s); }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("prefill launch: %s", hipGetErrorString(e)); return MILLION_ERR_LAUNCH; }

@@ -1947,11 +1947,16 @@ def test_prefill_attn_small_shapes(bs, nh, nhk, n_q, n_kv, q_pos0, causal, env):
     q = rs.standard_normal((bs, nh, n_q, 128)).astype(np.float16)
     k = rs.standard_normal((bs, nhk, n_kv, 128)).astype(np.float16)
     v = rs.standard_normal((bs, nhk, n_kv, 128)).astype(np.float16)
-    out = ops.prefill_attn(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(),
-                           causal=causal, q_pos0=q_pos0)
-    torch.cuda.synchronize()
     gold = _sdpa_ref_rows(q, k, v, list(range(n_q)), q_pos0, causal)
-    _check(out.cpu().numpy(), gold, f"prefill {bs} {nh} {nhk} {n_q} {n_kv}")
+    try:
+        for pol in (0, 64):      # the pipelined form (default at d = 128) and the plain one (million_set_force_generic(64))
+            ops.set_force_generic(pol)
+            out = ops.prefill_attn(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(),
+                                   causal=causal, q_pos0=q_pos0)
+            torch.cuda.synchronize()
+            _check(out.cpu().numpy(), gold, f"prefill {bs} {nh} {nhk} {n_q} {n_kv} policy {pol}")
+    finally:
+        ops.set_force_generic(0)
 
 
 def test_prefill_attn_strided_inputs_and_peaked_rows(env):
