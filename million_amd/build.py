@@ -16,7 +16,7 @@ CSRC = HERE / "csrc"
 LIB = HERE / "libmillion_hip.so"
 LIB_DEBUG_IDS = HERE / "libmillion_hip_dbgids.so"      # same sources with -DMILLION_DEBUG_CHECK_IDS (page ids bounds-checked)
 SOURCES = ["million_api.hip", "encode.hip", "attn_generic.hip", "attn_tile.hip", "attn_mfma.hip", "prefill.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value", "-Wno-tautological-bitwise-compare"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value", "-Wno-tautological-bitwise-compare", "-Wno-inline-asm"]
 
 
 def hipcc() -> str:

@@ -144,7 +144,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         bh = id % (int)gridDim.y;
         split = id / (int)gridDim.y;
     }
-    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;      // hk, bh: VIRTUAL when the launch splits the query heads of a kv head into parts
+    // real kv head / pair (what codes, page ids, window rows and the new rows are indexed by) and this workgroup's part
+    const int hkr = p.nhk_real ? hk % p.nhk_real : hk, part = p.nhk_real ? hk / p.nhk_real : 0;
+    const int bhr = p.nhk_real ? b * p.nhk_real + hkr : bh;
     const int G = p.G;
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     {
         int pgl = pg0 + lane * pg_step;
         pgl = pgl < p.n_pages_cap ? pgl : p.n_pages_cap - 1;
-        const long long idx = (long long)bh * p.n_pages_cap + pgl;
+        const long long idx = (long long)bhr * p.n_pages_cap + pgl;
         if (k_paged) vpk = ids64 ? (int)p.k_ids64[idx] : p.k_ids32[idx];
         if (v_ident) vpv = (int)idx;
         else vpv = ids64 ? (int)p.v_ids64[idx] : p.v_ids32[idx];
@@ -199,11 +202,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         Q[2 * v] = v2u{t[0], t[1]};
         Q[2 * v + 1] = v2u{t[2], t[3]};
     }
-    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
+    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1 && part == 0;      // wave-uniform
     h2 new_k = {}, new_v = {};
     if (append_wave && 2 * lane < DR) {
-        new_k = *(const h2 *)(p.k_new + (long long)bh * DR + 2 * lane);
-        new_v = *(const h2 *)(p.v_new + (long long)bh * DR + 2 * lane);
+        new_k = *(const h2 *)(p.k_new + (long long)bhr * DR + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bhr * DR + 2 * lane);
     }
     v4u tabk[NT], tabv[NT];
     const int rot = (blockIdx.x + 5 * blockIdx.y) & (NT - 1);
@@ -229,13 +232,13 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     // ---- residual window rows of this split (see load_res_tile) ----
     const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
     const bool has_res = kResRows * wave < rcnt;
-    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
-    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *kr = p.k_res + b * p.res_sb + hkr * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hkr * p.res_sh;
     LeanResTile<DD, DR> rt;
     v8f16 qb[DR / 32];      // the residual tile's query operand (16 x 16 x 32 layout: lane (q4, c16): head c16, dims (DD / 4) q4 + 8 s ..;
                             // d_m = 4: head c16 & 3 - the four column groups carry copies of the heads, as in the streaming kernel's form)
     if (has_res) {
-        lean_load_res_tile<DD, DM2, DR>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+        lean_load_res_tile<DD, DM2, DR>(p, bhr, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
         const int hq = DM2 ? n16 : hj;
         const f16 *qv = qrow + (hq < G ? hq : 0) * DR + (DR / 4) * kg;
 #pragma unroll
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
             _Pragma("unroll") for (int q_ = 0; q_ < NQ; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + k_lane_off + 16u * q_); \
         } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
             const int tu_ = t0 + jc_ * t_step;                                                                     \
-            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
+            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hkr * p.k_sh);                                               \
             const unsigned ro_ = (unsigned)min(tu_ + lane, T_ld - 1) << kLog2M;                                    \
             _Pragma("unroll") for (int q_ = 0; q_ < NQ; ++q_) ring[SL].k[q_] = *(gptr_v4u)(kb_ + ro_ + 16u * q_);  \
         }                                                                                                          \
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     if (append_wave && 2 * lane < DR) {
         int row_n = rstart + r_old;
         row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
-        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * DR + 2 * lane;
+        const long long o = b * p.res_sb + hkr * p.res_sh + (long long)row_n * DR + 2 * lane;
         *(h2 *)(p.k_res_w + o) = new_k;
         *(h2 *)(p.v_res_w + o) = new_v;
     }
@@ -621,8 +624,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         const int src = (32 * (n16 >> 3) + 2 * (n16 & 7) + (kg & 1)) << 2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int v0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, O.t[0][g]));
-            const int v1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, O.t[1][g]));
+            const float f0 = O.t[0][g], f1 = O.t[1][g];      // (copies: __builtin_bit_cast of a vector ELEMENT reads element 0 with this hipcc)
+            const int v0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, f0));
+            const int v1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, f1));
             O.t[0][g] = __builtin_bit_cast(float, (kg >> 1) ? v1 : v0);
             O.t[1][g] = 0.f;
         }

@@ -2094,8 +2094,27 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 // d = 64 with M = 32 / 16 (d_m = 2 / 4) and M = 64 (d_m = 1: run as d_m = 2 with every odd dim zero, attn_lean.h): the lean kernel
 // only (round 5; before: the tile kernel) - 256 centroids, up to 4 query heads per kv head
+// G = 6, 8 (12, 16) query heads per kv head: the launch runs 2 (4) VIRTUAL kv heads of 3 / 4 heads per real one (AttnParams::nhk_real;
+// the parts re-read the codes - from the XCD's L2 when they run together: the parts of a real head sit on one XCD).  The workspace
+// head is laid out for max(2048, bs * nh_k) pairs (million_api.hip): the virtual pairs must fit it.
+static int lean_hparts(const AttnParams &p) {
+    if (p.d != 64 || p.nhk_real) return 1;
+    const int P = (p.G == 6 || p.G == 8) ? 2 : (p.G == 12 || p.G == 16) ? 4 : 1;
+    return (P > 1 && (long long)p.bs * p.nh_k * P <= 2048) ? P : 1;
+}
+static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the lean kernel sees it
+    AttnParams p = p_in;
+    const int P = lean_hparts(p);
+    if (P > 1) {
+        p.nhk_real = p.nh_k;
+        p.nh_k *= P;
+        p.G /= P;
+        p.slot_floats = (p.G * p.d + 2 * p.G + 31) / 32 * 32;      // = slot_floats_for (million_api.hip)
+    }
+    return p;
+}
 static bool lean_d64_shape(const AttnParams &p) {
-    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && p.C == 256 && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
+    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && p.C == 256 && (p.G <= 4 || lean_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
 }
 bool attn_mfma_shape_ok(const AttnParams &p) {
     if (lean_d64_shape(p)) return true;
@@ -2160,8 +2179,10 @@ static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T
 
 // C = 128 runs on the streaming kernel only: without it (T = 0, more than 1M tokens) the call goes back to the caller
 // the lean kernel takes the call (launch_attn_mfma): pages of 64 / 128 tokens, streaming policy
-static bool lean_takes(const AttnParams &p) {
-    return attn_mfma_supported(p) && p.C == 256 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && g_mfma_policy == 0 &&
+static bool lean_takes(const AttnParams &p_in) {
+    if (!attn_mfma_supported(p_in)) return false;
+    const AttnParams p = lean_virtual(p_in);
+    return p.C == 256 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && g_mfma_policy == 0 &&
            mfma_stream_ok(p, mfma_splits(p)) && (p.d == 64 || (p.M == 64 || (p.M == 32 && !(g_mfma_form & 1))));
 }
 bool attn_mfma_handles(const AttnParams &p) {
@@ -2176,7 +2197,7 @@ bool attn_mfma_streams(const AttnParams &p) {
 }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
-    AttnParams p = p_in;
+    AttnParams p = p_in.d == 64 ? lean_virtual(p_in) : p_in;
     const int bh = p.bs * p.nh_k;
     const int ns = mfma_splits(p);
     const int units = p.T > 0 ? (p.T + 31) / 32 : 1;

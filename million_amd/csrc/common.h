@@ -52,6 +52,9 @@ struct AttnParams {
     const int *__restrict__ dev_lengths;
     int bs, nh, nh_k, G, d, M, C, dm;   // G: query heads of a kv head served by THIS launch (<= kMaxG)
     int Gt, g0;                         // nh / nh_k, and the first of them this launch serves (query-head groups > kMaxG: several launches)
+    int nhk_real;                       // 0, or (lean kernel, d = 64, G in {6, 8, 12, 16}) the real nh_k: the launch then treats each kv head as
+                                        // nh_k / nhk_real VIRTUAL kv heads of G query heads each (virtual kv head hk = part * nhk_real + real hk:
+                                        // the parts of a real head share an XCD), every tail structure indexed by the virtual pair
     int T, r, rstart, rcap;
     long long res_sb, res_sh, k_sb, k_sh, v_sb, v_sh;
     int k_paged, v_paged, page_size, ps_shift, n_pages_cap, ids64;
@@ -135,7 +138,9 @@ __device__ __forceinline__ float rows_sum(float x) {
     return __uint_as_float(b0) + __uint_as_float(b1);
 }
 // first query head (row of q / out) of kv head hk in this launch
-__device__ __forceinline__ int head0(const AttnParams &p, int hk) { return hk * p.Gt + p.g0; }
+__device__ __forceinline__ int head0(const AttnParams &p, int hk) {
+    return p.nhk_real ? (hk % p.nhk_real) * p.Gt + p.g0 + (hk / p.nhk_real) * p.G : hk * p.Gt + p.g0;
+}
 
 // Device-resident lengths are not trusted: T is clamped to the host bound the grid was sized for, r to the window
 // capacity (minus the row a fused append is about to add), the ring start to [0, cap).  Out-of-range values become a

@@ -148,9 +148,17 @@ static size_t attn_flag_bytes(int bs, int nh_k) {
     const size_t f = head_pairs(bs, nh_k) * 2 * kFlagWords * sizeof(unsigned);      // flags + XCD census line
     return (f + kCntBytes - 1) / kCntBytes * kCntBytes;
 }
+// floats of one (b, kv head, split) slot as the workspace is SIZED: the lean kernel may run G = 6, 8 (12, 16) heads as 2 (4) virtual kv
+// heads of G / 2 (G / 4) heads (attn_mfma.hip lean_virtual) - that many slots of the smaller group, each rounded up by itself
+static size_t slot_floats_sized(int G, int d) {
+    size_t n = slot_floats_for(G, d);
+    for (int P = 2; P <= 4; P *= 2)
+        if (G % P == 0 && (size_t)P * slot_floats_for(G / P, d) > n) n = (size_t)P * slot_floats_for(G / P, d);
+    return n;
+}
 static size_t attn_partial_bytes(int bs, int nh_k, int G, int d) {
     const size_t b = attn_cnt_bytes(bs, nh_k) + attn_flag_bytes(bs, nh_k) +
-                     (size_t)bs * nh_k * (kMaxSplits + 1) * slot_floats_for(G, d) * sizeof(float);
+                     (size_t)bs * nh_k * (kMaxSplits + 1) * slot_floats_sized(G, d) * sizeof(float);
     return (b + 255) / 256 * 256;
 }
 

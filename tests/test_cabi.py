@@ -91,10 +91,11 @@ def test_kernel_kind_policy_without_gpu(lib):
     assert kind(1, 32, 8, 0) == 5                      # nothing quantised yet: grouped MFMA kernel (window only)
     assert kind(1, 32, 8, 4096, paged=False) == 2      # the reference's 10-argument layout: V transposed first
     for d, M in ((128, 16), (64, 64), (64, 32), (64, 16)):
-        # d_m = 8 form of the streaming kernel, and (round 5) the lean kernel's d = 64 forms (d_m = 2 / 4): up to 4 query heads per kv head
-        fast = (d, M) in ((128, 16), (64, 32), (64, 16))
+        # d_m = 8 form of the streaming kernel, and (round 5) the lean kernel's d = 64 forms (d_m = 1 / 2 / 4): up to 4 query heads per kv head
+        fast = True      # round 5: d = 64 / M = 64 (d_m = 1) too, as d_m = 2 with every odd dim zero
         assert kind(1, 32, 8, 4096, d=d, M=M) == (1 if fast else 3)
-        assert kind(1, 128, 8, 4096, d=d, M=M) == 3    # 16 heads per kv head: still one tile-kernel launch
+        assert kind(1, 128, 8, 4096, d=d, M=M) == (1 if d == 64 else 3)    # 16 heads per kv head: d = 64: the lean kernel on 4 virtual kv
+        # heads of 4 query heads per real one; d = 128 / M = 16: still one tile-kernel launch
         assert kind(1, 32, 8, 4096, d=d, M=M, paged=False) == (2 if fast else 4)
     assert kind(1, 32, 8, 0, d=64, M=32) == 3          # nothing quantised yet at d = 64: the tile kernel (the lean kernel is not asked)
     assert kind(1, 32, 8, 4096, d=64, M=32, C=128) == 3

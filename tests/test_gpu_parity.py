@@ -1513,9 +1513,10 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
     t = _dev(torch, c)
     if T:
         # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4); d = 64 with M = 32 /
-        # 16 (d_m = 2 / 4), 256 centroids and up to 4 heads per kv head the lean kernel (round 5) on pages of 64 / 128 tokens
+        # 16 / 64 (d_m = 2 / 4 / 1), 256 centroids and up to 4 heads per kv head the lean kernel (round 5) on pages of 64 / 128 tokens
         stream16 = d == 128 and M == 16 and nh // nhk <= 4
-        lean64 = d == 64 and M in (32, 16) and C == 256 and nh // nhk <= 4
+        lean64 = d == 64 and C == 256 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)      # M = 64 (d_m = 1) runs as d_m = 2 with zero odd dims;
+        # 6 / 8 (12 / 16) heads per kv head as 2 (4) virtual kv heads of 3 / 4
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
                      v_codes=t["v_codes"]) == (2 if stream16 or lean64 else 4)
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
@@ -2352,6 +2353,45 @@ def test_attn_lean_kernel_unit_counts_and_forms(G, policy, env, oracle):
             _check(_run_rowmajor(torch, ops, c, M, C), gold, f"G={G} T={T} 10-arg layout")
     finally:
         ops.set_force_generic(0)
+    assert ops.tail_faults() == 0
+
+
+@pytest.mark.parametrize("M", [64, 32, 16], ids=["dm1-padded", "dm2", "dm4"])
+def test_attn_lean_kernel_d64_forms(M, env, oracle):
+    """d = 64 on the lean kernel: M = 32 / 16 (d_m = 2 / 4) and M = 64 (d_m = 1, run as d_m = 2 with every odd dim zero: codebooks
+    widened into LDS, accumulators packed back in front of the tail) over 0 .. 5 units per wave, windows of 1 .. 128 rows, every
+    head grouping up to 4, the fused append (its residual rows are read at d = 64)."""
+    torch, ops = env
+    C = 256
+    for G, nhk in ((4, 2), (3, 1), (1, 4), (2, 2), (8, 2), (6, 1), (16, 1), (12, 2)):      # 6 .. 16: virtual kv heads of 3 / 4 query heads
+        for T, r, ps in ((1, 1, 64), (64, 128, 64), (513, 64, 128), (1537, 31, 64), (4096 + 65, 127, 64), (5120 + 1, 2, 128)):
+            c = synth.attn_case(9500 + T + G + M, 1, G * nhk, nhk, 64, M, C, T, r, Lt=128)
+            gold = oracle.decode_attn(**c)
+            t = _dev(torch, c)
+            assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
+                         page_size=ps, n_pages_cap=(T + ps - 1) // ps) == 1
+            _check(_run_paged(torch, ops, oracle, c, M, C, ps, poison_out=True), gold, f"M={M} G={G} T={T} r={r} ps={ps} paged")
+            _check(_run_paged(torch, ops, oracle, c, M, C, ps, k_paged=False, i64=True), gold, f"M={M} G={G} T={T} row-major K, int64 ids")
+            _check(_run_rowmajor(torch, ops, c, M, C), gold, f"M={M} G={G} T={T} 10-arg layout")
+    # fused append at d = 64: the new row joins the window (and the attention) inside the launch; G = 8 runs two parts per kv head
+    # (only part 0 stores the row, both attend to it), two requests
+    for nhk, G, T, r in ((2, 4, 3000, 40), (2, 8, 3000, 40)):
+        c = synth.attn_case(9600 + M + G, 2, G * nhk, nhk, 64, M, C, T, r + 1, Lt=128)
+        gold = oracle.decode_attn(**c)
+        t = _dev(torch, c)
+        vpool, ids = oracle.v_rowmajor_to_pool(c["v_codes"], 64)
+        kpool, _ = oracle.k_rowmajor_to_pool(c["k_codes"], 64)
+        kp, vp = ops.prepare_cents(t["k_cents"], cache=False), ops.prepare_cents(t["v_cents"], cache=False)
+        k_res, v_res = t["k_res"].clone(), t["v_res"].clone()
+        k_new, v_new = k_res[:, :, r:r + 1].clone(), v_res[:, :, r:r + 1].clone()
+        k_res[:, :, r] = 0
+        v_res[:, :, r] = 0
+        ids_t = torch.from_numpy(ids.astype(np.int32)).cuda()
+        out = ops.pq_decode_attn(t["q"], torch.from_numpy(kpool).cuda(), torch.from_numpy(vpool).cuda(), kp, vp, k_res, v_res, r, M=M, C=C,
+                                 n_tokens=T, k_page_ids=ids_t, v_page_ids=ids_t, page_size=64, k_new=k_new, v_new=v_new)
+        torch.cuda.synchronize()
+        _check(out.cpu().numpy(), gold, f"M={M} G={G} fused append")
+        assert torch.equal(k_res[:, :, r], t["k_res"][:, :, r]) and torch.equal(v_res[:, :, r], t["v_res"][:, :, r])
     assert ops.tail_faults() == 0
 
 

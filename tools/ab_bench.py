@@ -134,7 +134,7 @@ for cfg in args.cfg:
     if args.bindings_10arg:
         tag = tag + " 10-arg"
     extra = f"   scalar fallback {scalar:8.1f} us ({scalar / best:5.1f}x)" if scalar else ""
-    if args.policy:
+    if args.policy and "policy" not in tag:
         tag = tag + f" policy {args.policy}"
     print(f"{tag:34s} bs={bs} nh={nh} nh_k={nhk} T={T:6d} d={d} M={M} C={C} kind={kind}: {best:6.2f} us/launch  {alg / best / 1e3:7.1f} GB/s ({alg / best / 8e6 * 100:4.1f}% of 8 TB/s)  rel diff vs cross-check {err:.1e}{extra}", flush=True)
     del states
