@@ -1642,7 +1642,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
         bh = id % (int)gridDim.y;
         split = id / (int)gridDim.y;
     }
-    const int b = bh / p.nh_k, hk = bh % p.nh_k;
+    const int b = bh / p.nh_k, hk = bh % p.nh_k;      // hk, bh: VIRTUAL when the launch splits the query heads of a kv head into parts
+    // (AttnParams::nhk_real): the real kv head / pair index codes, page ids, window rows and the new rows
+    const int hkr = p.nhk_real ? hk % p.nhk_real : hk, part = p.nhk_real ? hk / p.nhk_real : 0;
+    const int bhr = p.nhk_real ? b * p.nhk_real + hkr : bh;
     const int G = p.G;
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
@@ -1667,7 +1670,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     {
         int pgl = pg0 + lane * pg_step;
         pgl = pgl < p.n_pages_cap ? pgl : p.n_pages_cap - 1;
-        const long long idx = (long long)bh * p.n_pages_cap + pgl;
+        const long long idx = (long long)bhr * p.n_pages_cap + pgl;
         if (k_paged) vpk = ids64 ? (int)p.k_ids64[idx] : p.k_ids32[idx];
         if (v_ident) vpv = (int)idx;
         else vpv = ids64 ? (int)p.v_ids64[idx] : p.v_ids32[idx];
@@ -1690,11 +1693,11 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
             qb[s] = __builtin_bit_cast(v8f16, t);
         }
     }
-    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1;      // wave-uniform
+    const bool append_wave = p.k_new && split == 0 && wave == kNW - 1 && part == 0;      // wave-uniform
     h2 new_k = {}, new_v = {};
     if (append_wave) {
-        new_k = *(const h2 *)(p.k_new + (long long)bh * 128 + 2 * lane);
-        new_v = *(const h2 *)(p.v_new + (long long)bh * 128 + 2 * lane);
+        new_k = *(const h2 *)(p.k_new + (long long)bhr * 128 + 2 * lane);
+        new_v = *(const h2 *)(p.v_new + (long long)bhr * 128 + 2 * lane);
     }
     // both codebooks go out before anything that depends on a length or a page id (the CU's load path takes ~28 cycles
     // per 1-KiB wave request, in order: what is requested first is there first).  (Through round 2 the V codebook was
@@ -1723,10 +1726,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // ---- residual window rows of this split, dealt to the waves round-robin (see load_res_tile) ----
     const int rcnt = split < r ? (r - split + p.nsplit - 1) / p.nsplit : 0;
     const bool has_res = kResRows * wave < rcnt;
-    const f16 *kr = p.k_res + b * p.res_sb + hk * p.res_sh;
-    const f16 *vr = p.v_res + b * p.res_sb + hk * p.res_sh;
+    const f16 *kr = p.k_res + b * p.res_sb + hkr * p.res_sh;
+    const f16 *vr = p.v_res + b * p.res_sb + hkr * p.res_sh;
     ResTile rt;
-    if (has_res) load_res_tile<MSX>(p, bh, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
+    if (has_res) load_res_tile<MSX>(p, bhr, kr, vr, wave, rcnt, split, rstart, r_old, lane, rt);
 
     // ---- one unit's 16-byte requests into ring slot SL; J is wave-uniform; rounds past the wave's last unit
     //      re-request that unit (L2 hits, never consumed), so that no code load sits in a conditional ----
@@ -1749,7 +1752,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
                 ring[SL].k[g2] = *(KPtr)(kb_ + k_lane_off + ((4u * g2) << kLog2M));                                \
         } else {      /* row-major K: absolute row per lane, rows past T - 1 re-read it (masked later) */          \
             const int tu_ = t0 + jc_ * t_step;                                                                     \
-            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hk * p.k_sh);                                               \
+            kb_ = uniform_ptr(p.k_codes + b * p.k_sb + hkr * p.k_sh);                                               \
             _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2)                                                       \
                 ring[SL].k[g2] = *(KPtr)(kb_ + (((unsigned)min(tu_ + krow0 + 4 * g2, T_ld - 1) << kLog2M) +        \
                                                 (unsigned)(MS / 4) * q4));                                         \
@@ -1833,7 +1836,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     if (append_wave) {
         int row_n = rstart + r_old;
         row_n = row_n >= p.rcap ? row_n - p.rcap : row_n;
-        const long long o = b * p.res_sb + hk * p.res_sh + (long long)row_n * 128 + 2 * lane;
+        const long long o = b * p.res_sb + hkr * p.res_sh + (long long)row_n * 128 + 2 * lane;
         *(h2 *)(p.k_res_w + o) = new_k;
         *(h2 *)(p.v_res_w + o) = new_v;
     }
@@ -2094,11 +2097,12 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // flash_decoding_paged_v_*_Lt256 names) get at least ceil(rcap / 128) splits (launch_attn_mfma).
 // d = 64 with M = 32 / 16 (d_m = 2 / 4) and M = 64 (d_m = 1: run as d_m = 2 with every odd dim zero, attn_lean.h): the lean kernel
 // only (round 5; before: the tile kernel) - 256 centroids, up to 4 query heads per kv head
+static int g_mfma_policy = 0, g_tail_test = 0, g_lean_off = 0;      // A/B and test knobs: see set_mfma_policy below
 // G = 6, 8 (12, 16) query heads per kv head: the launch runs 2 (4) VIRTUAL kv heads of 3 / 4 heads per real one (AttnParams::nhk_real;
 // the parts re-read the codes - from the XCD's L2 when they run together: the parts of a real head sit on one XCD).  The workspace
 // head is laid out for max(2048, bs * nh_k) pairs (million_api.hip): the virtual pairs must fit it.
-static int lean_hparts(const AttnParams &p) {
-    if (p.d != 64 || p.nhk_real) return 1;
+static int lean_hparts(const AttnParams &p) {      // (the lean kernel's d = 64 forms and the streaming kernel's d = 128 / M = 16 form)
+    if (!(p.d == 64 || (p.d == 128 && p.M == 16)) || p.nhk_real || g_lean_off) return 1;      // (policy 16: no parts either - the tile kernel)
     const int P = (p.G == 6 || p.G == 8) ? 2 : (p.G == 12 || p.G == 16) ? 4 : 1;
     return (P > 1 && (long long)p.bs * p.nh_k * P <= 2048) ? P : 1;
 }
@@ -2118,8 +2122,8 @@ static bool lean_d64_shape(const AttnParams &p) {
 }
 bool attn_mfma_shape_ok(const AttnParams &p) {
     if (lean_d64_shape(p)) return true;
-    if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head
-        return (p.C == 256 || p.C == 128) && p.G <= 4 && p.rcap <= 4 * kNW * kResRows;
+    if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head (6 .. 16: as parts)
+        return (p.C == 256 || p.C == 128) && (p.G <= 4 || lean_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
     return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxGMfma && p.rcap <= 4 * kNW * kResRows;
 }
 
@@ -2140,7 +2144,6 @@ int read_tail_faults() {
 // g_tail_test (million_set_force_generic 4 / 8): the merge helpers give up at once - the last arriver's take-over path, for
 // tests: 1 = every give-up bit is set in the prologue, 2 = the helpers give up through the real path (no polls, then the atomic)
 // g_lean_off (million_set_force_generic 16): the lean kernel's shapes stay on the streaming kernel (A/B, tests of the parity-V form)
-static int g_mfma_policy = 0, g_tail_test = 0, g_lean_off = 0;
 // development A/B (dev_switches.h; environment MILLION_M32_PACKED=1 in a MILLION_DEV_BUILD): M = 32 keeps the packed form at G <= 4
 // too.  The constant 0 in the product build.
 static const int g_mfma_form = MILLION_DEV_M32_PACKED();
@@ -2187,17 +2190,23 @@ static bool lean_takes(const AttnParams &p_in) {
 }
 bool attn_mfma_handles(const AttnParams &p) {
     if (p.d == 64) return lean_takes(p);      // no other MFMA kernel of this file takes d = 64: the caller goes on to the tile kernel
-    if (p.M == 16) return attn_mfma_supported(p) && g_mfma_policy == 0 && mfma_stream_ok(p, mfma_splits(p));      // streaming kernel or not at all
+    if (p.M == 16) {      // streaming kernel or not at all
+        if (!attn_mfma_supported(p) || g_mfma_policy != 0) return false;
+        const AttnParams pv = lean_virtual(p);
+        return mfma_stream_ok(pv, mfma_splits(pv));
+    }
     return attn_mfma_supported(p) && (p.C != 128 || mfma_stream_ok(p, mfma_splits(p)));
 }
 // the call will run the STREAMING kernel (not the grouped fallback): million_attn_kernel_kind
 bool attn_mfma_streams(const AttnParams &p) {
     if (p.d == 64) return lean_takes(p);
-    return attn_mfma_supported(p) && g_mfma_policy == 0 && mfma_stream_ok(p, mfma_splits(p));
+    if (!attn_mfma_supported(p) || g_mfma_policy != 0) return false;
+    const AttnParams pv = lean_virtual(p);
+    return mfma_stream_ok(pv, mfma_splits(pv));
 }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
-    AttnParams p = p_in.d == 64 ? lean_virtual(p_in) : p_in;
+    AttnParams p = lean_virtual(p_in);      // (the identity unless the shape runs as head parts)
     const int bh = p.bs * p.nh_k;
     const int ns = mfma_splits(p);
     const int units = p.T > 0 ? (p.T + 31) / 32 : 1;

@@ -94,13 +94,14 @@ def test_kernel_kind_policy_without_gpu(lib):
         # d_m = 8 form of the streaming kernel, and (round 5) the lean kernel's d = 64 forms (d_m = 1 / 2 / 4): up to 4 query heads per kv head
         fast = True      # round 5: d = 64 / M = 64 (d_m = 1) too, as d_m = 2 with every odd dim zero
         assert kind(1, 32, 8, 4096, d=d, M=M) == (1 if fast else 3)
-        assert kind(1, 128, 8, 4096, d=d, M=M) == (1 if d == 64 else 3)    # 16 heads per kv head: d = 64: the lean kernel on 4 virtual kv
-        # heads of 4 query heads per real one; d = 128 / M = 16: still one tile-kernel launch
+        assert kind(1, 128, 8, 4096, d=d, M=M) == 1    # 16 heads per kv head: 4 virtual kv heads of 4 query heads per real one (round 5)
+        assert kind(1, 40, 8, 4096, d=d, M=M) == 3     # 5 heads per kv head: no even split - the tile kernel
         assert kind(1, 32, 8, 4096, d=d, M=M, paged=False) == (2 if fast else 4)
     assert kind(1, 32, 8, 0, d=64, M=32) == 3          # nothing quantised yet at d = 64: the tile kernel (the lean kernel is not asked)
     assert kind(1, 32, 8, 4096, d=64, M=32, C=128) == 3
     assert kind(1, 32, 8, 4096, d=128, M=16, C=128) == 1
-    assert kind(1, 64, 8, 4096, d=128, M=16) == 3      # 8 heads per kv head: tile kernel
+    assert kind(1, 64, 8, 4096, d=128, M=16) == 1      # 8 heads per kv head: two virtual kv heads of 4 on the streaming kernel (round 5)
+    assert kind(64, 256, 32, 4096, d=128, M=16) == 3   # ... unless the virtual pairs outgrow the workspace head (2048 records)
     assert kind(1, 32, 8, 4096, C=64) == 0             # off the build matrix: scalar kernel
 
 

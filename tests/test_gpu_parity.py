@@ -375,7 +375,7 @@ def test_attn_replicated_head_forms(M, nh, nhk, env, oracle):
     """The streaming kernel's d_m = 4 / d_m = 8 forms (M = 32 / 16 at up to 4 query heads per kv head: query heads replicated over
     the column groups of the score tile, gathered V entries as the value product's B operand): every group size 1..4, paged and
     row-major, ring start > 0, three fused-append steps with device lengths; 8 heads per kv head take the packed form (M = 32) /
-    the tile kernel (M = 16) and must agree too."""
+    run as two virtual kv heads of 4 query heads (M = 16, round 5; before: the tile kernel) and must agree too."""
     torch, ops = env
     bs, T, r0, ps, C = 2, 2500, 37, 64, 256
     c = synth.attn_case(7700 + M + nh, bs, nh, nhk, 128, M, C, T, r0, Lt=128)
@@ -386,7 +386,7 @@ def test_attn_replicated_head_forms(M, nh, nhk, env, oracle):
     desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r0, k_paged=True, v_paged=True,
                               page_size=ps, n_pages_cap=(T + ps - 1) // ps)
     from million_amd import _lib
-    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == (3 if (M == 16 and nh // nhk > 4) else 1)
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1      # (M = 16 at 8 heads per kv head: two virtual kv heads of 4, round 5)
     # fused append over three steps, device lengths, ring start 100
     kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
     rs = np.random.RandomState(3)
@@ -1514,7 +1514,7 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
     if T:
         # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4); d = 64 with M = 32 /
         # 16 / 64 (d_m = 2 / 4 / 1), 256 centroids and up to 4 heads per kv head the lean kernel (round 5) on pages of 64 / 128 tokens
-        stream16 = d == 128 and M == 16 and nh // nhk <= 4
+        stream16 = d == 128 and M == 16 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)
         lean64 = d == 64 and C == 256 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)      # M = 64 (d_m = 1) runs as d_m = 2 with zero odd dims;
         # 6 / 8 (12 / 16) heads per kv head as 2 (4) virtual kv heads of 3 / 4
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
@@ -1620,14 +1620,21 @@ def test_attn_tile_kernel_peaked_and_long(env, oracle):
     c["k_codes"][0, 0, 2500, :] = 0
     c["k_codes"][0, 0, 10, :M // 2] = 0
     _check(_run_paged(torch, ops, oracle, c, M, C, 64), oracle.decode_attn(**c), "tile peaked")
-    c = synth.attn_case(7201, 1, 16, 2, 128, 16, 256, 40000, 128, Lt=128)
-    _check(_run_paged(torch, ops, oracle, c, 16, 256, 128), oracle.decode_attn(**c), "tile long d128M16 G8")
-    c = synth.attn_case(7202, 2, 8, 8, 64, 16, 128, 33000, 77, Lt=128)
-    _check(_run_rowmajor(torch, ops, c, 16, 128), oracle.decode_attn(**c), "tile long d64M16 bs2")
-    # d = 64 with more than 128 tiles per CU: the two-workgroups-of-four-waves variant (smaller launches use 16 waves)
-    for M, seed in ((32, 7203), (64, 7204)):
-        c = synth.attn_case(seed, 3, 16, 8, 64, M, 256, 24000, 50, Lt=128)
-        _check(_run_paged(torch, ops, oracle, c, M, 256, 64), oracle.decode_attn(**c), f"tile d64M{M} bs3 4-wave variant")
+    # (round 5 moved these shapes to the streaming / lean kernels - 8 heads per kv head as two virtual kv heads of 4; policy 16 keeps
+    # them on the tile kernel: both must agree with the oracle)
+    try:
+        for pol in (16, 0):
+            ops.set_force_generic(pol)
+            c = synth.attn_case(7201, 1, 16, 2, 128, 16, 256, 40000, 128, Lt=128)
+            _check(_run_paged(torch, ops, oracle, c, 16, 256, 128), oracle.decode_attn(**c), f"long d128M16 G8 policy {pol}")
+            c = synth.attn_case(7202, 2, 8, 8, 64, 16, 128, 33000, 77, Lt=128)
+            _check(_run_rowmajor(torch, ops, c, 16, 128), oracle.decode_attn(**c), f"long d64M16 bs2 policy {pol}")
+            # d = 64 with more than 128 tiles per CU: the two-workgroups-of-four-waves variant (smaller launches use 16 waves)
+            for M, seed in ((32, 7203), (64, 7204)):
+                c = synth.attn_case(seed, 3, 16, 8, 64, M, 256, 24000, 50, Lt=128)
+                _check(_run_paged(torch, ops, oracle, c, M, 256, 64), oracle.decode_attn(**c), f"d64M{M} bs3 4-wave variant policy {pol}")
+    finally:
+        ops.set_force_generic(0)
 
 
 def test_bindings_names_on_tile_shapes(env, oracle):
