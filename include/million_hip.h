@@ -228,21 +228,22 @@ int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh
                               int64_t v_stride_b, int64_t v_stride_h, million_stream_t stream);
 
 /* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = streaming MFMA kernels (d = 128 with M in {64, 32}, and
- * d = 128 / M = 16 with up to 4 query heads per kv head; any batch and any context up to 1M tokens per (b, kv head): calls with
- * more than 64 rounds per wave get more splits; with 256 centroids, up to 4 query heads per kv head and pages of 64 / 128 tokens
- * the "lean" form of it runs - csrc/attn_lean.h - which also takes d = 64 with M in {32, 16}),
+ * d = 128 / M = 16 with 1 .. 4, 6, 8, 12 or 16 query heads per kv head; any batch and any context up to 1M tokens per (b, kv head):
+ * calls with more than 64 rounds per wave get more splits; with 256 centroids, up to 4 query heads per kv head and pages of 64 / 128
+ * tokens the "lean" form of it runs - csrc/attn_lean.h - which also takes d = 64 with M in {64, 32, 16} at 1 .. 4, 6, 8, 12 or 16
+ * query heads per kv head: 6 and more run as 2 or 4 virtual kv heads of 3 / 4 query heads, while bs * nh_k * parts <= 2048),
  * 2 = the same after transposing row-major V codes into workspace scratch (one extra launch), 3 = tile MFMA kernel
- * (d = 64 with M in {16, 32, 64}; d = 128 with M = 16 and more than 4 query heads per kv head), 4 = the same after the
- * transpose, 5 = the grouped MFMA kernel (the streaming kernel's fallback on its M = 64 / 32 shapes: no quantised token yet,
- * or more than 1M tokens), 0 = scalar fallback (anything else the descriptor allows: C not 128 / 256, paged K with row-major
- * V, ...), -1 = bad descriptor. */
+ * (d = 64 with 128 centroids, 5 / 7 / other query heads per kv head, 32-token pages; d = 128 with M = 16 and such head groups),
+ * 4 = the same after the transpose, 5 = the grouped MFMA kernel (the streaming kernel's fallback on its M = 64 / 32 shapes: no
+ * quantised token yet, or more than 1M tokens), 0 = scalar fallback (anything else the descriptor allows: C not 128 / 256, paged K
+ * with row-major V, ...), -1 = bad descriptor. */
 int million_attn_kernel_kind(const million_attn_desc *desc);
 /* Kernel choice for A/B measurements and tests: 0 = auto (default), 1 = generic kernel only, 2 = MFMA grouped kernel
  * only (never the streaming one), 4 = auto, but the helper workgroups of the split merge give up at once (exercises the
  * last arriver's take-over path of the MFMA kernels' tail: every give-up bit is set before the launch's first ticket),
  * 8 = auto, but the helpers have no patience: each gives up through the real path (its atomic on the ticket word) unless
  * every workgroup has already taken its ticket, 16 = auto, but the shapes of the lean kernel (csrc/attn_lean.h) stay on the
- * streaming / tile kernels (A/B and the tests of those kernels' forms), 64 = auto, but million_prefill_attn runs its plain
+ * streaming / tile kernels and no call runs as virtual kv heads (A/B and the tests of those kernels' forms), 64 = auto, but million_prefill_attn runs its plain
  * tile loop at d = 128 instead of the pipelined one (csrc/prefill.hip; A/B and the tests of both forms). */
 void million_set_force_generic(int on);
 
