@@ -590,7 +590,8 @@ def lengths_advance(dev_lengths: torch.Tensor, n_flushed: int, resid_cap: int) -
 def set_force_generic(on) -> None:
     """0 / False = auto, 1 / True = scalar fallback kernel only, 2 = grouped MFMA kernel instead of the streaming one, 4 = auto
     with the merge helpers giving up at once (every give-up bit preset), 8 = auto with helpers that have no patience (each gives
-    up through the real atomic path) - million_hip.h: million_set_force_generic."""
+    up through the real atomic path), 16 = auto, but the lean kernel's shapes stay on the streaming / tile kernels and nothing runs as
+    virtual kv heads, 64 = auto, but prompt attention runs its plain tile loop at d = 128 - million_hip.h: million_set_force_generic."""
     L.load().million_set_force_generic(int(on))
 
 

@@ -385,11 +385,14 @@ def test_make_install_pth_resolves_bindings_without_pythonpath(tmp_path):
     site_dir = tmp_path / "site"
     r = subprocess.run([sys.executable, str(root / "tools" / "install_pth.py"), "--target", str(site_dir)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert (site_dir / "million_hip.pth").read_text().strip() == str(root)
+    # the .pth names build/site (two symlinks), not the checkout root: tests / tools / oracle do not become importable
+    assert (site_dir / "million_hip.pth").read_text().strip() == str(root / "build" / "site")
+    assert sorted(p.name for p in (root / "build" / "site").iterdir()) == ["bindings", "million_amd"]
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     code = ("import site, sys; site.addsitedir(%r); import bindings, million_amd; "
             "print(bindings.__file__); "
-            "assert hasattr(bindings, 'flash_decoding_allocated_buffer_f16u8_Ns32Lt128d128M64C256')") % str(site_dir)
+            "assert %r not in sys.path; "
+            "assert hasattr(bindings, 'flash_decoding_allocated_buffer_f16u8_Ns32Lt128d128M64C256')") % (str(site_dir), str(root))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env)
     assert r.returncode == 0, r.stderr
     assert str(root) in r.stdout
