@@ -347,6 +347,13 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
         const f16 *qp = p.q + b * p.q_sb + head * p.q_sh + (long long)qr * p.q_sn + 8 * hh;
 #pragma unroll
         for (int s = 0; s < DS; ++s) qf[s] = *(const v8h *)(qp + 16 * s);
+        // Q carries the softmax scale and log2 e (one more fp16 rounding of Q: rel-L2 against fp32 1.6e-4 -> 1.8e-4, bar 1e-3), and
+        // a half's score products start from -reference instead of 0: the accumulator IS the exponent, p = exp2(S') with no
+        // fused multiply-add per score (16 of ~164 vector instructions per half and wave; +2 % measured, profiles/r05_prefill.txt)
+#pragma unroll
+        for (int s = 0; s < DS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (f16)((float)qf[s][e] * p.scale_log2e);
     }
     const int wg_q_hi = qb * QB + QB - 1 < p.n_q - 1 ? qb * QB + QB - 1 : p.n_q - 1;
     int kv_end_wg = p.causal ? p.q_pos0 + wg_q_hi + 1 : p.n_kv;
@@ -381,8 +388,7 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) O[i][j] = 0.f;
-    const float c = p.scale_log2e, inv_c = 1.0f / p.scale_log2e;
-    float m_ref = -INFINITY, neg_ref = 0.f, thr_raw = -INFINITY, l_run = 0.f;
+    float m_ref = -INFINITY, neg_ref = 0.f, thr_rel = -INFINITY, l_run = 0.f;      // thr_rel: 8 once a reference exists (scores are relative to it)
     const int qd = (lane >> 2) & 3, pp = lane & 3, g16 = (lane >> 4) & 1;
 
     // wave-uniform predicates of half h (keys 32 h .. 32 h + 31) for this wave
@@ -395,15 +401,19 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
 #pragma unroll
         for (int j = 0; j < 16; ++j) S[j] = (j & 3) + 8 * (j >> 2) <= rel ? S[j] : -INFINITY;
     };
-    // the reference decision for a half whose raw per-lane maximum is mx (both half-waves hold the same query rows)
-    auto decide = [&](float mx) {
+    v16f NEG;      // -reference of the lane's query row in every register: the initial accumulator of a half's score products
+#pragma unroll
+    for (int j = 0; j < 16; ++j) NEG[j] = 0.f;
+    // the reference decision for a half whose per-lane maximum (relative to the current reference) is mx (both half-waves hold the
+    // same query rows); Nx = that half's scores, already computed against the old reference: they move with it
+    auto decide = [&](float mx, v16f &Nx) {
         {
             const v2u ex = swap32_self(__float_as_uint(mx));
             const unsigned e0 = ex[0], e1 = ex[1];
             mx = fmaxf(__uint_as_float(e0), __uint_as_float(e1));
         }
-        if (__any(mx > thr_raw)) {
-            const float m_new = fmaxf(m_ref, mx * c);
+        if (__any(mx > thr_rel)) {
+            const float m_new = fmaxf(m_ref, mx - neg_ref);      // mx is relative to the old reference (neg_ref = -m_safe)
             const float m_safe = m_new > -INFINITY ? m_new : 0.f;
             const float alpha = __builtin_amdgcn_exp2f(m_ref - m_safe);
 #pragma unroll
@@ -412,8 +422,11 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
                 for (int j = 0; j < 16; ++j) O[i][j] *= alpha;
             l_run *= alpha;
             m_ref = m_new;
+            const float shift = -m_safe - neg_ref;      // the scores already computed move to the new reference
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { Nx[j] += shift; NEG[j] = -m_safe; }
             neg_ref = -m_safe;
-            thr_raw = (m_new + 8.0f) * inv_c;
+            thr_rel = 8.0f;
         }
     };
     // Fragment addresses as 8 + 8 lane constants with everything else in the ds_read immediates (the plain kernel keeps 16 + 32
@@ -454,10 +467,24 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
         float mx = SA[0];
 #pragma unroll
         for (int j = 1; j < 16; ++j) mx = fmaxf(mx, SA[j]);
-        decide(mx);
+        decide(mx, SA);
     }
     // One half-step: half h (scores in C, reference decided; its V rows: buffer HQ >> 1, half HQ & 1) and half h + 1 (scores into N;
     // its K rows: quarter (HQ + 1) & 3).  HQ = h & 3 is a compile-time constant: the tile loop is unrolled by two.
+    // iteration t: half-steps 2 t and 2 t + 1; its DMA: K halves 2 t + 3, 2 t + 4 (quarters last read in iteration t - 1) and V tile t + 1
+#if MILLION_EXP & 512
+#define PF_DMA(T) (void)0
+#else
+#define PF_DMA(T) dma_k_half(2 * (T) + 3); dma_k_half(2 * (T) + 4); dma_v_tile((T) + 1)
+#endif
+#if MILLION_EXP & 1024
+#define PF_SYNC() (void)0
+#else
+#define PF_SYNC() dma_wait(); __syncthreads()
+#endif
+    // (Tried, no change: an iteration's first half-step requesting its first three K operands BEFORE it issues the iteration's DMA
+    // pieces, and the second half-step's in the first one's last gaps - the LDS round trip at a phase's start is not what the
+    // loop waits for: 1060 vs 1062 TFLOP/s, profiles/r05_prefill.txt.)
     auto half_step = [&](auto hqc, v16f &C, v16f &N, const int h) {
         constexpr int HQ = decltype(hqc)::value, HN = (HQ + 1) & 3, BUFV = HQ >> 1, JT = HQ & 1;
         const bool nxt_live = live(h + 1);
@@ -470,15 +497,15 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
             pv4s lo[3], hi[3];
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
-                if (s == 0) N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                if (s == 0) N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], NEG, 0, 0, 0);
                 else N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], N, 0, 0, 0);
                 PF_PIN(N);
                 if (s + 3 < DS) af[s % 3] = PF_KFRAG(HN, (s + 3) & 7);
                 else { lo[s - 5] = PF_VFRAG(BUFV, JT, 0, 0, (s - 5) & 3); hi[s - 5] = PF_VFRAG(BUFV, JT, 0, 1, (s - 5) & 3); }
 #if MILLION_EXP & 256
-                const float p0 = fmaf(C[2 * s], c, neg_ref), p1 = fmaf(C[2 * s + 1], c, neg_ref);
+                const float p0 = C[2 * s] + 1.0f, p1 = C[2 * s + 1] + 1.0f;
 #else
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(C[2 * s], c, neg_ref)), p1 = __builtin_amdgcn_exp2f(fmaf(C[2 * s + 1], c, neg_ref));
+                const float p0 = __builtin_amdgcn_exp2f(C[2 * s]), p1 = __builtin_amdgcn_exp2f(C[2 * s + 1]);
 #endif
                 ls += p0;
                 ls += p1;
@@ -502,21 +529,10 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
                 PF_PIN(mx);
             }
             l_run += ls;
-            decide(mx);
+            decide(mx, N);
         }
         cur_live = nxt_live;
     };
-    // iteration t: half-steps 2 t and 2 t + 1; its DMA: K halves 2 t + 3, 2 t + 4 (quarters last read in iteration t - 1) and V tile t + 1
-#if MILLION_EXP & 512
-#define PF_DMA(T) (void)0
-#else
-#define PF_DMA(T) dma_k_half(2 * (T) + 3); dma_k_half(2 * (T) + 4); dma_v_tile((T) + 1)
-#endif
-#if MILLION_EXP & 1024
-#define PF_SYNC() (void)0
-#else
-#define PF_SYNC() dma_wait(); __syncthreads()
-#endif
     for (int t = 0; t < nt; t += 2) {
         PF_DMA(t);
         half_step(std::integral_constant<int, 0>{}, SA, SB, 2 * t);
