@@ -14,6 +14,8 @@
 //     prefill.hip     1  no exponentials, 2 no tile barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
 //                                                                                                 profiles/r03_prefill.txt, r04_prefill.txt
 //                   256  pipelined kernel: no exponentials, 512 no tile DMA behind the prologue, 1024 no tile wait/barrier  profiles/r05_prefill.txt
+//                  2048  pipelined kernel: per-phase shader-clock sums of workgroup 0's waves, written into their own query rows (tools/prefill_prof.py)
+//                 16384  pipelined kernel: only waves 0 - 3 compute (one computing wave per SIMD; its partner issues DMA and joins barriers)
 //   MILLION_TILE_PROF      attn_tile.hip: per-tile shader-clock stamps (tools/tile_prof.py)
 //   MILLION_DEV_M32_PACKED() run-time A/B (environment MILLION_M32_PACKED=1, dev builds only): M = 32 keeps the packed value form
 //                          at up to 4 query heads per kv head too (the product build takes the d_m = 4 form there and the

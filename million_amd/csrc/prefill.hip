@@ -361,7 +361,11 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
     const int nt = kv_end_wg > 0 ? (kv_end_wg + kKV - 1) / kKV : 0;
     const int nh2 = 2 * nt;                                              // 32-key halves of this workgroup
     const int w_pos_lo = p.q_pos0 + q_lo, w_pos_hi = p.q_pos0 + q_lo + 31;
+#if MILLION_EXP & 16384
+    const bool wave_live = q_lo < p.n_q && wave < 4;      // diagnostic: one computing wave per SIMD (its partner only issues DMA and joins barriers)
+#else
     const bool wave_live = q_lo < p.n_q;
+#endif
     const f16 *kbase = p.k + b * p.k_sb + hk * p.k_sh;
     const f16 *vbase = p.v + b * p.v_sb + hk * p.v_sh;
     // one-KiB pieces (4 rows of a tile): a K half = pieces 8 jt .. 8 jt + 7 of its tile: one per wave; a V tile = 16: two per wave
@@ -450,6 +454,16 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
 #define PF_KFRAG(HQ, S) __builtin_bit_cast(v8h, ((lds_v4u_p)(size_t)ka[S])[(2u * kTileBytes * ((HQ) >> 1) + 256u * 32u * ((HQ) & 1)) / 16])
 #define PF_VFRAG(BUFV, JT, KS, HI, BLK) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)va[HI][BLK] + (2u * kTileBytes * (BUFV) + kTileBytes + 256u * (32u * (JT) + 16u * (KS))) / 8)
 
+#if MILLION_EXP & 2048
+    // phase clock of this wave (tools/prefill_prof.py): cycles since the previous stamp are added to slot I.  s_memtime needs
+    // lgkmcnt(0), so a stamp also drains the wave's LDS reads - the profile runs a few percent slow and over-states the slot behind
+    // a stamp that cuts a read-ahead.  Slots: 0 DMA issue, 1 phase 1, 2 mask, 3 phase 2, 4 reference decision, 5 DMA wait + barrier
+    unsigned long long pt_last = __builtin_readcyclecounter();
+    unsigned pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PT(I) { const unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[I] += (unsigned)(n_ - pt_last); pt_last = n_; }
+#else
+#define PT(I)
+#endif
     // prologue: K halves 0, 1, 2 and V tile 0
     dma_k_half(0); dma_k_half(1); dma_k_half(2); dma_v_tile(0);
 #pragma unroll
@@ -485,9 +499,13 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
     // (Tried, no change: an iteration's first half-step requesting its first three K operands BEFORE it issues the iteration's DMA
     // pieces, and the second half-step's in the first one's last gaps - the LDS round trip at a phase's start is not what the
     // loop waits for: 1060 vs 1062 TFLOP/s, profiles/r05_prefill.txt.)
+    // (Tried, slower: a wave's four DMA pieces issued inside the MFMA gaps of the iteration's first half-step, two per phase, at
+    // wave-dependent gaps - the issue stall moves into the phases and grows: phase 1 732 -> 982 cycles, phase 2 330 -> 488 per half-step
+    // for 250 saved: 1024 vs 1055 TFLOP/s, profiles/r05_prefill.txt.  A burst outside the phases is the cheapest place.)
     auto half_step = [&](auto hqc, v16f &C, v16f &N, const int h) {
         constexpr int HQ = decltype(hqc)::value, HN = (HQ + 1) & 3, BUFV = HQ >> 1, JT = HQ & 1;
         const bool nxt_live = live(h + 1);
+
         if (cur_live) {      // a wave's last live half runs the same code: the scores of the half behind it are masked whole
             float ls = 0.f, mx = -INFINITY;
             unsigned pw8[8];
@@ -514,7 +532,9 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
                 pw8[s] = __builtin_bit_cast(unsigned, t2);
                 asm volatile("" : "+v"(pw8[s]), "+v"(ls));
             }
+            PT(1)
             if (!nxt_live || masked(h + 1)) mask_half(h + 1, N);
+            PT(2)
             // phase 2: value products of half h (operands three steps ahead) | running maximum of half h + 1's raw scores
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -528,23 +548,40 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(N[2 * i]), "v"(N[2 * i + 1]));
                 PF_PIN(mx);
             }
+            PT(3)
             l_run += ls;
             decide(mx, N);
+            PT(4)
         }
         cur_live = nxt_live;
     };
+    PT(7)
     for (int t = 0; t < nt; t += 2) {
         PF_DMA(t);
+        PT(0)
         half_step(std::integral_constant<int, 0>{}, SA, SB, 2 * t);
         half_step(std::integral_constant<int, 1>{}, SB, SA, 2 * t + 1);
         PF_SYNC();
+        PT(5)
         if (t + 1 < nt) {
             PF_DMA(t + 1);
+            PT(0)
             half_step(std::integral_constant<int, 2>{}, SA, SB, 2 * t + 2);
             half_step(std::integral_constant<int, 3>{}, SB, SA, 2 * t + 3);
             PF_SYNC();
+            PT(5)
         }
     }
+#if MILLION_EXP & 2048
+    if (blockIdx.x == 0 && lane < 8) {      // into this wave's own first query row (read into registers long ago; nobody else reads it)
+        unsigned *dst = (unsigned *)(p.q + b * p.q_sb + head * p.q_sh + (long long)q_lo * p.q_sn);
+        unsigned v_ = pt_acc[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v_ = lane == i ? pt_acc[i] : v_;
+        dst[lane] = v_;
+    }
+#endif
+#undef PT
 #undef PF_DMA
 #undef PF_SYNC
 #undef PF_KFRAG
