@@ -146,8 +146,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     }
     const int b = bh / p.nh_k, hk = bh % p.nh_k;      // hk, bh: VIRTUAL when the launch splits the query heads of a kv head into parts
     // real kv head / pair (what codes, page ids, window rows and the new rows are indexed by) and this workgroup's part
-    const int hkr = p.nhk_real ? hk % p.nhk_real : hk, part = p.nhk_real ? hk / p.nhk_real : 0;
-    const int bhr = p.nhk_real ? b * p.nhk_real + hkr : bh;
+    const int part = head_part(p, hk), hkr = hk - part * p.nhk_mul;
+    const int bhr = bh - (b * p.hparts_m1 + part) * p.nhk_mul;
     const int G = p.G;
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);

@@ -1644,8 +1644,8 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     const int b = bh / p.nh_k, hk = bh % p.nh_k;      // hk, bh: VIRTUAL when the launch splits the query heads of a kv head into parts
     // (AttnParams::nhk_real): the real kv head / pair index codes, page ids, window rows and the new rows
-    const int hkr = p.nhk_real ? hk % p.nhk_real : hk, part = p.nhk_real ? hk / p.nhk_real : 0;
-    const int bhr = p.nhk_real ? b * p.nhk_real + hkr : bh;
+    const int part = head_part(p, hk), hkr = hk - part * p.nhk_mul;
+    const int bhr = bh - (b * p.hparts_m1 + part) * p.nhk_mul;
     const int G = p.G;
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
@@ -2102,7 +2102,7 @@ static int g_mfma_policy = 0, g_tail_test = 0, g_lean_off = 0;      // A/B and t
 // the parts re-read the codes - from the XCD's L2 when they run together: the parts of a real head sit on one XCD).  The workspace
 // head is laid out for max(2048, bs * nh_k) pairs (million_api.hip): the virtual pairs must fit it.
 static int lean_hparts(const AttnParams &p) {      // (the lean kernel's d = 64 forms and the streaming kernel's d = 128 / M = 16 form)
-    if (!(p.d == 64 || (p.d == 128 && p.M == 16)) || p.nhk_real || g_lean_off) return 1;      // (policy 16: no parts either - the tile kernel)
+    if (!(p.d == 64 || (p.d == 128 && p.M == 16)) || p.nhk_mul || g_lean_off) return 1;      // (policy 16: no parts either - the tile kernel)
     const int P = (p.G == 6 || p.G == 8) ? 2 : (p.G == 12 || p.G == 16) ? 4 : 1;
     return (P > 1 && (long long)p.bs * p.nh_k * P <= 2048) ? P : 1;
 }
@@ -2110,7 +2110,8 @@ static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the
     AttnParams p = p_in;
     const int P = lean_hparts(p);
     if (P > 1) {
-        p.nhk_real = p.nh_k;
+        p.nhk_real = p.nhk_mul = p.nh_k;
+        p.hparts_m1 = P - 1;
         p.nh_k *= P;
         p.G /= P;
         p.slot_floats = (p.G * p.d + 2 * p.G + 31) / 32 * 32;      // = slot_floats_for (million_api.hip)

@@ -52,9 +52,11 @@ struct AttnParams {
     const int *__restrict__ dev_lengths;
     int bs, nh, nh_k, G, d, M, C, dm;   // G: query heads of a kv head served by THIS launch (<= kMaxG)
     int Gt, g0;                         // nh / nh_k, and the first of them this launch serves (query-head groups > kMaxG: several launches)
-    int nhk_real;                       // 0, or (lean kernel, d = 64, G in {6, 8, 12, 16}) the real nh_k: the launch then treats each kv head as
-                                        // nh_k / nhk_real VIRTUAL kv heads of G query heads each (virtual kv head hk = part * nhk_real + real hk:
-                                        // the parts of a real head share an XCD), every tail structure indexed by the virtual pair
+    // Query-head parts (lean kernel at d = 64, streaming kernel at d = 128 / M = 16; G in {6, 8, 12, 16}): the launch treats each kv head as
+    // hparts_m1 + 1 VIRTUAL kv heads of G query heads each (virtual kv head hk = part * real nh_k + real hk: the parts of a real head
+    // share an XCD), every tail structure indexed by the virtual pair.  No split: nhk_real = 2^28 (no hk reaches it: part = 0 without a
+    // branch or a division), nhk_mul = 0, hparts_m1 = 0
+    int nhk_real, nhk_mul, hparts_m1;
     int T, r, rstart, rcap;
     long long res_sb, res_sh, k_sb, k_sh, v_sb, v_sh;
     int k_paged, v_paged, page_size, ps_shift, n_pages_cap, ids64;
@@ -138,8 +140,12 @@ __device__ __forceinline__ float rows_sum(float x) {
     return __uint_as_float(b0) + __uint_as_float(b1);
 }
 // first query head (row of q / out) of kv head hk in this launch
+__device__ __forceinline__ int head_part(const AttnParams &p, int hk) {      // which part of its real kv head a (virtual) kv head is: three compares
+    return (hk >= p.nhk_real) + (hk >= 2 * p.nhk_real) + (hk >= 3 * p.nhk_real);
+}
 __device__ __forceinline__ int head0(const AttnParams &p, int hk) {
-    return p.nhk_real ? (hk % p.nhk_real) * p.Gt + p.g0 + (hk / p.nhk_real) * p.G : hk * p.Gt + p.g0;
+    const int part = head_part(p, hk);
+    return (hk - part * p.nhk_mul) * p.Gt + p.g0 + part * p.G;
 }
 
 // Device-resident lengths are not trusted: T is clamped to the host bound the grid was sized for, r to the window

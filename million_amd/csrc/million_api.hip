@@ -171,6 +171,7 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     p.G = p.Gt < kMaxGMfma ? p.Gt : kMaxGMfma;      // in one launch, the tile / scalar kernels kMaxG = 8; bigger groups run as several
                                               // launches (attn_impl).  G = heads of one launch, sized here for the largest
     p.g0 = 0;
+    p.nhk_real = 1 << 28; p.nhk_mul = 0; p.hparts_m1 = 0;      // no query-head parts (attn_mfma.hip lean_virtual sets them)
     if (p.M <= 0 || p.d <= 0 || p.d % p.M || p.M % 4) { set_error("attn: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
     p.dm = p.d / p.M;
     if (p.C < 2 || p.C > 256) { set_error("attn: C=%d (uint8 codes)", p.C); return MILLION_ERR_SHAPE; }
