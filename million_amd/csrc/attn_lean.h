@@ -31,7 +31,7 @@
 //     two tokens ANDed with the lane's dim-position masks.
 // Per 64 tokens and wave at d = 128 / M = 64: 128 LDS gathers (as before), 48 MFMAs (32 of them 4 x 4 x 4: 512 matrix-pipe cycles;
 // parity-V: 768), ~195 vector instructions (parity-V: ~300), 16 swizzles.
-// Shapes: C = 256, up to 4 query heads per kv head, pages of 64 or 128 tokens (or row-major K); d = 128 with M = 64 / 32 and
+// Shapes: C = 256 / 128, up to 4 query heads per kv head (d = 64: also 6 .. 16 as parts), pages of 64 or 128 tokens (or row-major K); d = 128 with M = 64 / 32 and
 // d = 64 with M = 32 / 16 (d_m = 2 / 4).  Everything else stays on the streaming / tile kernels (million_set_force_generic(16)
 // keeps the lean shapes there too: A/B and tests).
 // =====================================================================================================
@@ -208,15 +208,20 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         new_k = *(const h2 *)(p.k_new + (long long)bhr * DR + 2 * lane);
         new_v = *(const h2 *)(p.v_new + (long long)bhr * DR + 2 * lane);
     }
+    // 128 centroids (wave-uniform): half the pieces; the K rows are spread to the 256-entry row stride the gathers use (below)
+    const bool c128 = p.C == 128;
+    const int nt_rt = c128 ? NT / 2 : NT;
     v4u tabk[NT], tabv[NT];
-    const int rot = (blockIdx.x + 5 * blockIdx.y) & (NT - 1);
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & (nt_rt - 1);
     {
         const v4u *ks = (const v4u *)p.k_tab;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) tabk[i] = ks[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
+        for (int i = 0; i < NT; ++i)
+            if (i < nt_rt) tabk[i] = ks[((i + rot) & (nt_rt - 1)) * (kNW * 64) + tid];
         const v4u *vs = (const v4u *)p.v_tab_col;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) tabv[i] = vs[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
+        for (int i = 0; i < NT; ++i)
+            if (i < nt_rt) tabv[i] = vs[((i + rot) & (nt_rt - 1)) * (kNW * 64) + tid];
     }
     if (p.dev_lengths)
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
@@ -289,6 +294,27 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     {
         v4u *ld = (v4u *)smem;
         v4u *ldv = (v4u *)(smem + kVBase);
+        if (c128) {
+            // K row image [m][128][d_m]: row m goes to the 256-entry row stride of the C = 256 image (codes are < 128: the second half of
+            // a row is never read); V col image [c][m][d_m]: the first 128 rows, placed as for C = 256
+            constexpr unsigned RBS = 128u * (DR / MS) * 2u;               // source bytes of a K row
+            constexpr unsigned LROW = 256u * (DD / MS) * 2u;              // its LDS stride
+#pragma unroll
+            for (int i = 0; i < NT / 2; ++i) {
+                const unsigned pi_ = ((i + rot) & (NT / 2 - 1)) * (kNW * 64) + tid;
+                const unsigned off = pi_ * 16u, kd = (off / RBS) * LROW + (off % RBS) * (PAD ? 2u : 1u);
+                if constexpr (PAD) {
+                    *(v4u *)(smem + kd) = v4u{tabk[i][0] & 0xffffu, tabk[i][0] >> 16, tabk[i][1] & 0xffffu, tabk[i][1] >> 16};
+                    *(v4u *)(smem + kd + 16) = v4u{tabk[i][2] & 0xffffu, tabk[i][2] >> 16, tabk[i][3] & 0xffffu, tabk[i][3] >> 16};
+                    ldv[2 * pi_] = v4u{tabv[i][0] & 0xffffu, tabv[i][0] >> 16, tabv[i][1] & 0xffffu, tabv[i][1] >> 16};
+                    ldv[2 * pi_ + 1] = v4u{tabv[i][2] & 0xffffu, tabv[i][2] >> 16, tabv[i][3] & 0xffffu, tabv[i][3] >> 16};
+                } else {
+                    *(v4u *)(smem + kd) = tabk[i];
+                    if constexpr (DD == 128) ldv[pi_] = tabv[i];
+                    else *(v4u *)(smem + kVBase + ((off >> 7) << 8) + (off & 127u)) = tabv[i];
+                }
+            }
+        } else
         if constexpr (PAD) {      // 2-byte entries -> (value, 0) words: piece pi of an image becomes pieces 2 pi, 2 pi + 1 of its LDS copy
 #pragma unroll
             for (int i = 0; i < NT; ++i) {

@@ -2119,7 +2119,7 @@ static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the
     return p;
 }
 static bool lean_d64_shape(const AttnParams &p) {
-    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && p.C == 256 && (p.G <= 4 || lean_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
+    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && (p.C == 256 || p.C == 128) && (p.G <= 4 || lean_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
 }
 bool attn_mfma_shape_ok(const AttnParams &p) {
     if (lean_d64_shape(p)) return true;
@@ -2186,7 +2186,7 @@ static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T
 static bool lean_takes(const AttnParams &p_in) {
     if (!attn_mfma_supported(p_in)) return false;
     const AttnParams p = lean_virtual(p_in);
-    return p.C == 256 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && g_mfma_policy == 0 &&
+    return (p.C == 256 || p.C == 128) && p.G <= 4 && p.page_size >= 64 && !g_lean_off && g_mfma_policy == 0 &&
            mfma_stream_ok(p, mfma_splits(p)) && (p.d == 64 || (p.M == 64 || (p.M == 32 && !(g_mfma_form & 1))));
 }
 bool attn_mfma_handles(const AttnParams &p) {
@@ -2288,20 +2288,22 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<16, 1>), grid, block, kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_stream_kernel<16, 2>), grid, block, kLdsBytes, s, p);
     } else
+    // lean kernel (round 5): 64-token units, lane = token; C = 256 and (its table copy spreads the K rows) C = 128
+    if (g_mfma_policy == 0 && stream_ok && p.M == 64 && p.G <= 4 && p.page_size >= 64 && !g_lean_off) {
+        if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0>), grid, block, kLdsBytes, s, p);
+        else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1>), grid, block, kLdsBytes, s, p);
+        else hipLaunchKernelGGL((attn_lean_kernel<2>), grid, block, kLdsBytes, s, p);
+    } else if (g_mfma_policy == 0 && stream_ok && p.M == 32 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && !(g_mfma_form & 1)) {      // d_m = 4
+        if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32>), grid, block, kLdsBytes, s, p);
+        else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32>), grid, block, kLdsBytes, s, p);
+        else hipLaunchKernelGGL((attn_lean_kernel<2, 32>), grid, block, kLdsBytes, s, p);
+    } else
     if (p.C == 128) {      // 128 centroids per subspace (reference setup.py:15): streaming kernel by run-time layout flags only
         if (!stream_ok) return kAttnNotHandled;      // T = 0 or more than 64 rounds per wave: the caller takes the generic kernel
         if (p.M == 64) hipLaunchKernelGGL((attn_stream_kernel<64, 2, 7>), grid, block, kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_stream_kernel<32, 2, 7>), grid, block, kLdsBytes, s, p);
     } else if (g_mfma_policy == 0 && stream_ok) {
-        if (p.M == 64 && p.G <= 4 && p.page_size >= 64 && !g_lean_off) {      // lean kernel (round 5): 64-token units, lane = token
-            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0>), grid, block, kLdsBytes, s, p);
-            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1>), grid, block, kLdsBytes, s, p);
-            else hipLaunchKernelGGL((attn_lean_kernel<2>), grid, block, kLdsBytes, s, p);
-        } else if (p.M == 32 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && !(g_mfma_form & 1)) {      // lean kernel, d_m = 4
-            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32>), grid, block, kLdsBytes, s, p);
-            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32>), grid, block, kLdsBytes, s, p);
-            else hipLaunchKernelGGL((attn_lean_kernel<2, 32>), grid, block, kLdsBytes, s, p);
-        } else if (p.M == 64) {
+        if (p.M == 64) {
             if (mode == 0) hipLaunchKernelGGL((attn_stream_kernel<64, 0>), grid, block, kLdsBytes, s, p);
             else if (mode == 1) hipLaunchKernelGGL((attn_stream_kernel<64, 1>), grid, block, kLdsBytes, s, p);
             else hipLaunchKernelGGL((attn_stream_kernel<64, 2>), grid, block, kLdsBytes, s, p);

@@ -98,7 +98,7 @@ def test_kernel_kind_policy_without_gpu(lib):
         assert kind(1, 40, 8, 4096, d=d, M=M) == 3     # 5 heads per kv head: no even split - the tile kernel
         assert kind(1, 32, 8, 4096, d=d, M=M, paged=False) == (2 if fast else 4)
     assert kind(1, 32, 8, 0, d=64, M=32) == 3          # nothing quantised yet at d = 64: the tile kernel (the lean kernel is not asked)
-    assert kind(1, 32, 8, 4096, d=64, M=32, C=128) == 3
+    assert kind(1, 32, 8, 4096, d=64, M=32, C=128) == 1        # (round 5: 128 centroids on the lean kernel too)
     assert kind(1, 32, 8, 4096, d=128, M=16, C=128) == 1
     assert kind(1, 64, 8, 4096, d=128, M=16) == 1      # 8 heads per kv head: two virtual kv heads of 4 on the streaming kernel (round 5)
     assert kind(64, 256, 32, 4096, d=128, M=16) == 3   # ... unless the virtual pairs outgrow the workspace head (2048 records)

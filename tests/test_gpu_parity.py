@@ -1515,7 +1515,7 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
         # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4); d = 64 with M = 32 /
         # 16 / 64 (d_m = 2 / 4 / 1), 256 centroids and up to 4 heads per kv head the lean kernel (round 5) on pages of 64 / 128 tokens
         stream16 = d == 128 and M == 16 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)
-        lean64 = d == 64 and C == 256 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)      # M = 64 (d_m = 1) runs as d_m = 2 with zero odd dims;
+        lean64 = d == 64 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)      # M = 64 (d_m = 1) runs as d_m = 2 with zero odd dims; C = 128 too;
         # 6 / 8 (12 / 16) heads per kv head as 2 (4) virtual kv heads of 3 / 4
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
                      v_codes=t["v_codes"]) == (2 if stream16 or lean64 else 4)
@@ -2372,6 +2372,7 @@ def test_attn_lean_kernel_d64_forms(M, env, oracle):
     C = 256
     for G, nhk in ((4, 2), (3, 1), (1, 4), (2, 2), (8, 2), (6, 1), (16, 1), (12, 2)):      # 6 .. 16: virtual kv heads of 3 / 4 query heads
         for T, r, ps in ((1, 1, 64), (64, 128, 64), (513, 64, 128), (1537, 31, 64), (4096 + 65, 127, 64), (5120 + 1, 2, 128)):
+            C = 128 if (T + G) % 3 == 0 else 256      # 128 centroids: the K rows are spread to the 256-entry stride on their way into LDS
             c = synth.attn_case(9500 + T + G + M, 1, G * nhk, nhk, 64, M, C, T, r, Lt=128)
             gold = oracle.decode_attn(**c)
             t = _dev(torch, c)
@@ -2380,6 +2381,7 @@ def test_attn_lean_kernel_d64_forms(M, env, oracle):
             _check(_run_paged(torch, ops, oracle, c, M, C, ps, poison_out=True), gold, f"M={M} G={G} T={T} r={r} ps={ps} paged")
             _check(_run_paged(torch, ops, oracle, c, M, C, ps, k_paged=False, i64=True), gold, f"M={M} G={G} T={T} row-major K, int64 ids")
             _check(_run_rowmajor(torch, ops, c, M, C), gold, f"M={M} G={G} T={T} 10-arg layout")
+    C = 256
     # fused append at d = 64: the new row joins the window (and the attention) inside the launch; G = 8 runs two parts per kv head
     # (only part 0 stores the row, both attend to it), two requests
     for nhk, G, T, r in ((2, 4, 3000, 40), (2, 8, 3000, 40)):
