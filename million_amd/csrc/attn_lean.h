@@ -31,8 +31,8 @@
 //     two tokens ANDed with the lane's dim-position masks.
 // Per 64 tokens and wave at d = 128 / M = 64: 128 LDS gathers (as before), 48 MFMAs (32 of them 4 x 4 x 4: 512 matrix-pipe cycles;
 // parity-V: 768), ~195 vector instructions (parity-V: ~300), 16 swizzles.
-// Shapes: C = 256 / 128, up to 4 query heads per kv head (d = 64: also 6 .. 16 as parts), pages of 64 or 128 tokens (or row-major K); d = 128 with M = 64 / 32 and
-// d = 64 with M = 32 / 16 (d_m = 2 / 4).  Everything else stays on the streaming / tile kernels (million_set_force_generic(16)
+// Shapes: C = 256 / 128, up to 4 query heads per kv head (d = 64: also 6 .. 16 as parts), pages of 64 or 128 tokens (or row-major K);
+// d = 128 with M = 64 / 32 and d = 64 with M = 64 / 32 / 16 (d_m = 1 as zero-padded d_m = 2, 2, 4).  Everything else stays on the streaming / tile kernels (million_set_force_generic(16)
 // keeps the lean shapes there too: A/B and tests).
 // =====================================================================================================
 
