@@ -228,12 +228,12 @@ int million_transpose_v_codes(const void *v_codes, void *v_pages, int bs, int nh
                               int64_t v_stride_b, int64_t v_stride_h, million_stream_t stream);
 
 /* Which kernel million_pq_decode_attn would pick for a descriptor: 1 = streaming MFMA kernels (d = 128 with M in {64, 32}, and
- * d = 128 / M = 16 with 1 .. 4, 6, 8, 12 or 16 query heads per kv head; any batch and any context up to 1M tokens per (b, kv head):
+ * d = 128 / M = 16 with up to 16 query heads per kv head; any batch and any context up to 1M tokens per (b, kv head):
  * calls with more than 64 rounds per wave get more splits; with 256 or 128 centroids, up to 4 query heads per kv head and pages of 64 / 128
- * tokens the "lean" form of it runs - csrc/attn_lean.h - which also takes d = 64 with M in {64, 32, 16} at 1 .. 4, 6, 8, 12 or 16
- * query heads per kv head: 6 and more run as 2 or 4 virtual kv heads of 3 / 4 query heads, while bs * nh_k * parts <= 2048),
+ * tokens the "lean" form of it runs - csrc/attn_lean.h - which also takes d = 64 with M in {64, 32, 16} at up to 16
+ * query heads per kv head: 5 and more run as ceil(G / 4) virtual kv heads of 3 / 4 query heads, while bs * nh_k * parts <= 2048),
  * 2 = the same after transposing row-major V codes into workspace scratch (one extra launch), 3 = tile MFMA kernel
- * (d = 64 with 5 / 7 / other query heads per kv head or on 32-token pages; d = 128 with M = 16 and such head groups),
+ * (d = 64 on 32-token pages; d = 64 or d = 128 / M = 16 with more than 2048 virtual (b, kv head) pairs),
  * 4 = the same after the transpose, 5 = the grouped MFMA kernel (the streaming kernel's fallback on its M = 64 / 32 shapes: no
  * quantised token yet, or more than 1M tokens), 0 = scalar fallback (anything else the descriptor allows: C not 128 / 256, paged K
  * with row-major V, ...), -1 = bad descriptor. */

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     // real kv head / pair (what codes, page ids, window rows and the new rows are indexed by) and this workgroup's part
     const int part = head_part(p, hk), hkr = hk - part * p.nhk_mul;
     const int bhr = bh - (b * p.hparts_m1 + part) * p.nhk_mul;
-    const int G = p.G;
+    const int G = p.nhk_mul ? min(p.G, p.G_all - part * p.G) : p.G;      // (the last part of an odd head group holds fewer)
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
     const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;

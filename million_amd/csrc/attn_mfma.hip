@@ -1009,15 +1009,15 @@ __device__ __forceinline__ void merge_and_publish(const AttnParams &p, char *sme
                 *(h4 *)(p.out + ((long long)b * p.nh + head0(p, hk)) * DD + 4 * q) = o;
             } else if (same_xcd) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 0);
-                if (q % (DD / 4) == 0) {
-                    dst[G * DD + g] = Mx;
-                    dst[G * DD + G + g] = lsum;
+                if (q % (DD / 4) == 0) {      // (a slot is laid out for p.G heads: the last part of an odd head group holds fewer, G < p.G)
+                    dst[p.G * DD + g] = Mx;
+                    dst[p.G * DD + p.G + g] = lsum;
                 }
             } else {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc), rsrc, q * 16, 0, 16 /* sc1 */);
                 if (q % (DD / 4) == 0) {
-                    st_agent(dst + G * DD + g, Mx);
-                    st_agent(dst + G * DD + G + g, lsum);
+                    st_agent(dst + p.G * DD + g, Mx);
+                    st_agent(dst + p.G * DD + p.G + g, lsum);
                 }
             }
         }
@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     // (AttnParams::nhk_real): the real kv head / pair index codes, page ids, window rows and the new rows
     const int part = head_part(p, hk), hkr = hk - part * p.nhk_mul;
     const int bhr = bh - (b * p.hparts_m1 + part) * p.nhk_mul;
-    const int G = p.G;
+    const int G = p.nhk_mul ? min(p.G, p.G_all - part * p.G) : p.G;      // (the last part of an odd head group holds fewer)
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
     const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;
@@ -2098,12 +2098,12 @@ int launch_rows_reduce_check(const float *in, float *out_max, float *out_sum, hi
 // d = 64 with M = 32 / 16 (d_m = 2 / 4) and M = 64 (d_m = 1: run as d_m = 2 with every odd dim zero, attn_lean.h): the lean kernel
 // only (round 5; before: the tile kernel) - 256 centroids, up to 4 query heads per kv head
 static int g_mfma_policy = 0, g_tail_test = 0, g_lean_off = 0;      // A/B and test knobs: see set_mfma_policy below
-// G = 6, 8 (12, 16) query heads per kv head: the launch runs 2 (4) VIRTUAL kv heads of 3 / 4 heads per real one (AttnParams::nhk_real;
+// 5 .. 16 query heads per kv head: the launch runs ceil(G / 4) VIRTUAL kv heads of ceil(G / parts) heads per real one (AttnParams::nhk_real;
 // the parts re-read the codes - from the XCD's L2 when they run together: the parts of a real head sit on one XCD).  The workspace
 // head is laid out for max(2048, bs * nh_k) pairs (million_api.hip): the virtual pairs must fit it.
 static int lean_hparts(const AttnParams &p) {      // (the lean kernel's d = 64 forms and the streaming kernel's d = 128 / M = 16 form)
     if (!(p.d == 64 || (p.d == 128 && p.M == 16)) || p.nhk_mul || g_lean_off) return 1;      // (policy 16: no parts either - the tile kernel)
-    const int P = (p.G == 6 || p.G == 8) ? 2 : (p.G == 12 || p.G == 16) ? 4 : 1;
+    const int P = p.G > 4 && p.G <= 16 ? (p.G + 3) / 4 : 1;      // 5 .. 8 heads: 2 parts, 9 .. 12: 3, 13 .. 16: 4
     return (P > 1 && (long long)p.bs * p.nh_k * P <= 2048) ? P : 1;
 }
 static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the lean kernel sees it
@@ -2113,7 +2113,8 @@ static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the
         p.nhk_real = p.nhk_mul = p.nh_k;
         p.hparts_m1 = P - 1;
         p.nh_k *= P;
-        p.G /= P;
+        p.G_all = p.G;
+        p.G = (p.G + P - 1) / P;      // 3 or 4 heads per part; the last part: G_all - (P - 1) G >= 1
         p.slot_floats = (p.G * p.d + 2 * p.G + 31) / 32 * 32;      // = slot_floats_for (million_api.hip)
     }
     return p;

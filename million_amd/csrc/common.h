@@ -52,11 +52,12 @@ struct AttnParams {
     const int *__restrict__ dev_lengths;
     int bs, nh, nh_k, G, d, M, C, dm;   // G: query heads of a kv head served by THIS launch (<= kMaxG)
     int Gt, g0;                         // nh / nh_k, and the first of them this launch serves (query-head groups > kMaxG: several launches)
-    // Query-head parts (lean kernel at d = 64, streaming kernel at d = 128 / M = 16; G in {6, 8, 12, 16}): the launch treats each kv head as
-    // hparts_m1 + 1 VIRTUAL kv heads of G query heads each (virtual kv head hk = part * real nh_k + real hk: the parts of a real head
+    // Query-head parts (lean kernel at d = 64, streaming kernel at d = 128 / M = 16; 5 .. 16 query heads per kv head): the launch treats each
+    // kv head as hparts_m1 + 1 = ceil(heads / 4) VIRTUAL kv heads of G = ceil(heads / parts) query heads each (the last part: what is left) (virtual kv head hk = part * real nh_k + real hk: the parts of a real head
     // share an XCD), every tail structure indexed by the virtual pair.  No split: nhk_real = 2^28 (no hk reaches it: part = 0 without a
     // branch or a division), nhk_mul = 0, hparts_m1 = 0
     int nhk_real, nhk_mul, hparts_m1;
+    int G_all;                          // query heads per REAL kv head of this launch when it runs as parts (the last part may hold fewer than G)
     int T, r, rstart, rcap;
     long long res_sb, res_sh, k_sb, k_sh, v_sb, v_sh;
     int k_paged, v_paged, page_size, ps_shift, n_pages_cap, ids64;

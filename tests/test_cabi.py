@@ -94,8 +94,8 @@ def test_kernel_kind_policy_without_gpu(lib):
         # d_m = 8 form of the streaming kernel, and (round 5) the lean kernel's d = 64 forms (d_m = 1 / 2 / 4): up to 4 query heads per kv head
         fast = True      # round 5: d = 64 / M = 64 (d_m = 1) too, as d_m = 2 with every odd dim zero
         assert kind(1, 32, 8, 4096, d=d, M=M) == (1 if fast else 3)
-        assert kind(1, 128, 8, 4096, d=d, M=M) == 1    # 16 heads per kv head: 4 virtual kv heads of 4 query heads per real one (round 5)
-        assert kind(1, 40, 8, 4096, d=d, M=M) == 3     # 5 heads per kv head: no even split - the tile kernel
+        assert kind(1, 128, 8, 4096, d=d, M=M) == 1    # 16 heads per kv head: 4 virtual kv heads of 4 query heads per real one (round 5; 5 .. 16: ceil(G / 4) parts)
+        assert kind(1, 40, 8, 4096, d=d, M=M) == 1     # 5 heads per kv head: parts of 3 + 2
         assert kind(1, 32, 8, 4096, d=d, M=M, paged=False) == (2 if fast else 4)
     assert kind(1, 32, 8, 0, d=64, M=32) == 3          # nothing quantised yet at d = 64: the tile kernel (the lean kernel is not asked)
     assert kind(1, 32, 8, 4096, d=64, M=32, C=128) == 1        # (round 5: 128 centroids on the lean kernel too)

@@ -370,7 +370,7 @@ def test_fused_append(paged, use_dl, env, oracle):
 
 
 @pytest.mark.parametrize("M", [32, 16], ids=["M32-d4form", "M16-d8form"])
-@pytest.mark.parametrize("nh,nhk", [(2, 2), (4, 2), (6, 2), (8, 2), (16, 2)], ids=["G1", "G2", "G3", "G4", "G8"])
+@pytest.mark.parametrize("nh,nhk", [(2, 2), (4, 2), (6, 2), (8, 2), (16, 2), (10, 2), (14, 2), (13, 1)], ids=["G1", "G2", "G3", "G4", "G8", "G5", "G7", "G13"])
 def test_attn_replicated_head_forms(M, nh, nhk, env, oracle):
     """The streaming kernel's d_m = 4 / d_m = 8 forms (M = 32 / 16 at up to 4 query heads per kv head: query heads replicated over
     the column groups of the score tile, gathered V entries as the value product's B operand): every group size 1..4, paged and
@@ -386,7 +386,7 @@ def test_attn_replicated_head_forms(M, nh, nhk, env, oracle):
     desc = ops.make_attn_desc(t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r0, k_paged=True, v_paged=True,
                               page_size=ps, n_pages_cap=(T + ps - 1) // ps)
     from million_amd import _lib
-    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1      # (M = 16 at 8 heads per kv head: two virtual kv heads of 4, round 5)
+    assert _lib.load().million_attn_kernel_kind(ctypes.byref(desc)) == 1      # (M = 16 at 5 .. 16 heads per kv head: ceil(G / 4) virtual kv heads, round 5)
     # fused append over three steps, device lengths, ring start 100
     kp, vp = ops.prepare_cents(t["k_cents"]), ops.prepare_cents(t["v_cents"])
     rs = np.random.RandomState(3)
@@ -1514,9 +1514,9 @@ def test_attn_tile_kernel_shapes(d, M, C, T, r, nh, nhk, bs, env, oracle):
     if T:
         # d = 128 / M = 16 with up to 4 query heads per kv head runs the streaming kernel's d_m = 8 form (round 4); d = 64 with M = 32 /
         # 16 / 64 (d_m = 2 / 4 / 1), 256 centroids and up to 4 heads per kv head the lean kernel (round 5) on pages of 64 / 128 tokens
-        stream16 = d == 128 and M == 16 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)
-        lean64 = d == 64 and nh // nhk in (1, 2, 3, 4, 6, 8, 12, 16)      # M = 64 (d_m = 1) runs as d_m = 2 with zero odd dims; C = 128 too;
-        # 6 / 8 (12 / 16) heads per kv head as 2 (4) virtual kv heads of 3 / 4
+        stream16 = d == 128 and M == 16 and nh // nhk <= 16
+        lean64 = d == 64 and nh // nhk <= 16      # M = 64 (d_m = 1) runs as d_m = 2 with zero odd dims; C = 128 too;
+        # 5 .. 16 heads per kv head as ceil(G / 4) virtual kv heads of 3 / 4 (the last part: what is left)
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_codes=t["k_codes"],
                      v_codes=t["v_codes"]) == (2 if stream16 or lean64 else 4)
         assert _kind(torch, ops, t["q"], t["k_res"], nh_k=nhk, M=M, C=C, n_tokens=T, r=r, k_paged=True, v_paged=True,
@@ -2370,7 +2370,7 @@ def test_attn_lean_kernel_d64_forms(M, env, oracle):
     head grouping up to 4, the fused append (its residual rows are read at d = 64)."""
     torch, ops = env
     C = 256
-    for G, nhk in ((4, 2), (3, 1), (1, 4), (2, 2), (8, 2), (6, 1), (16, 1), (12, 2)):      # 6 .. 16: virtual kv heads of 3 / 4 query heads
+    for G, nhk in ((4, 2), (3, 1), (1, 4), (2, 2), (8, 2), (6, 1), (16, 1), (12, 2), (5, 2), (7, 1), (9, 1), (13, 1)):      # 5 .. 16: virtual kv heads of 3 / 4 query heads
         for T, r, ps in ((1, 1, 64), (64, 128, 64), (513, 64, 128), (1537, 31, 64), (4096 + 65, 127, 64), (5120 + 1, 2, 128)):
             C = 128 if (T + G) % 3 == 0 else 256      # 128 centroids: the K rows are spread to the 256-entry stride on their way into LDS
             c = synth.attn_case(9500 + T + G + M, 1, G * nhk, nhk, 64, M, C, T, r, Lt=128)
@@ -2384,7 +2384,7 @@ def test_attn_lean_kernel_d64_forms(M, env, oracle):
     C = 256
     # fused append at d = 64: the new row joins the window (and the attention) inside the launch; G = 8 runs two parts per kv head
     # (only part 0 stores the row, both attend to it), two requests
-    for nhk, G, T, r in ((2, 4, 3000, 40), (2, 8, 3000, 40)):
+    for nhk, G, T, r in ((2, 4, 3000, 40), (2, 8, 3000, 40), (2, 7, 3000, 40)):
         c = synth.attn_case(9600 + M + G, 2, G * nhk, nhk, 64, M, C, T, r + 1, Lt=128)
         gold = oracle.decode_attn(**c)
         t = _dev(torch, c)
