@@ -2101,14 +2101,14 @@ static int g_mfma_policy = 0, g_tail_test = 0, g_lean_off = 0;      // A/B and t
 // 5 .. 16 query heads per kv head: the launch runs ceil(G / 4) VIRTUAL kv heads of ceil(G / parts) heads per real one (AttnParams::nhk_real;
 // the parts re-read the codes - from the XCD's L2 when they run together: the parts of a real head sit on one XCD).  The workspace
 // head is laid out for max(2048, bs * nh_k) pairs (million_api.hip): the virtual pairs must fit it.
-static int lean_hparts(const AttnParams &p) {      // (the lean kernel's d = 64 forms and the streaming kernel's d = 128 / M = 16 form)
+static int mfma_hparts(const AttnParams &p) {      // (the lean kernel's d = 64 forms and the streaming kernel's d = 128 / M = 16 form)
     if (!(p.d == 64 || (p.d == 128 && p.M == 16)) || p.nhk_mul || g_lean_off) return 1;      // (policy 16: no parts either - the tile kernel)
     const int P = p.G > 4 && p.G <= 16 ? (p.G + 3) / 4 : 1;      // 5 .. 8 heads: 2 parts, 9 .. 12: 3, 13 .. 16: 4
     return (P > 1 && (long long)p.bs * p.nh_k * P <= 2048) ? P : 1;
 }
-static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the lean kernel sees it
+static AttnParams mfma_virtual(const AttnParams &p_in) {      // the call as the lean kernel sees it
     AttnParams p = p_in;
-    const int P = lean_hparts(p);
+    const int P = mfma_hparts(p);
     if (P > 1) {
         p.nhk_real = p.nhk_mul = p.nh_k;
         p.hparts_m1 = P - 1;
@@ -2120,12 +2120,12 @@ static AttnParams lean_virtual(const AttnParams &p_in) {      // the call as the
     return p;
 }
 static bool lean_d64_shape(const AttnParams &p) {
-    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && (p.C == 256 || p.C == 128) && (p.G <= 4 || lean_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
+    return p.d == 64 && (p.M == 64 || p.M == 32 || p.M == 16) && (p.C == 256 || p.C == 128) && (p.G <= 4 || mfma_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
 }
 bool attn_mfma_shape_ok(const AttnParams &p) {
     if (lean_d64_shape(p)) return true;
     if (p.d == 128 && p.M == 16)      // d_m = 8 form of the streaming kernel (round 4): up to 4 query heads per kv head (6 .. 16: as parts)
-        return (p.C == 256 || p.C == 128) && (p.G <= 4 || lean_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
+        return (p.C == 256 || p.C == 128) && (p.G <= 4 || mfma_hparts(p) > 1) && p.rcap <= 4 * kNW * kResRows;
     return p.d == 128 && (p.M == 64 || p.M == 32) && (p.C == 256 || p.C == 128) && p.G <= kMaxGMfma && p.rcap <= 4 * kNW * kResRows;
 }
 
@@ -2186,7 +2186,7 @@ static bool mfma_stream_ok(const AttnParams &p, int ns) { return p.T > 0 && (p.T
 // the lean kernel takes the call (launch_attn_mfma): pages of 64 / 128 tokens, streaming policy
 static bool lean_takes(const AttnParams &p_in) {
     if (!attn_mfma_supported(p_in)) return false;
-    const AttnParams p = lean_virtual(p_in);
+    const AttnParams p = mfma_virtual(p_in);
     return (p.C == 256 || p.C == 128) && p.G <= 4 && p.page_size >= 64 && !g_lean_off && g_mfma_policy == 0 &&
            mfma_stream_ok(p, mfma_splits(p)) && (p.d == 64 || (p.M == 64 || (p.M == 32 && !(g_mfma_form & 1))));
 }
@@ -2194,7 +2194,7 @@ bool attn_mfma_handles(const AttnParams &p) {
     if (p.d == 64) return lean_takes(p);      // no other MFMA kernel of this file takes d = 64: the caller goes on to the tile kernel
     if (p.M == 16) {      // streaming kernel or not at all
         if (!attn_mfma_supported(p) || g_mfma_policy != 0) return false;
-        const AttnParams pv = lean_virtual(p);
+        const AttnParams pv = mfma_virtual(p);
         return mfma_stream_ok(pv, mfma_splits(pv));
     }
     return attn_mfma_supported(p) && (p.C != 128 || mfma_stream_ok(p, mfma_splits(p)));
@@ -2203,12 +2203,12 @@ bool attn_mfma_handles(const AttnParams &p) {
 bool attn_mfma_streams(const AttnParams &p) {
     if (p.d == 64) return lean_takes(p);
     if (!attn_mfma_supported(p) || g_mfma_policy != 0) return false;
-    const AttnParams pv = lean_virtual(p);
+    const AttnParams pv = mfma_virtual(p);
     return mfma_stream_ok(pv, mfma_splits(pv));
 }
 
 int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
-    AttnParams p = lean_virtual(p_in);      // (the identity unless the shape runs as head parts)
+    AttnParams p = mfma_virtual(p_in);      // (the identity unless the shape runs as head parts)
     const int bh = p.bs * p.nh_k;
     const int ns = mfma_splits(p);
     const int units = p.T > 0 ? (p.T + 31) / 32 : 1;

@@ -149,7 +149,7 @@ static size_t attn_flag_bytes(int bs, int nh_k) {
     return (f + kCntBytes - 1) / kCntBytes * kCntBytes;
 }
 // floats of one (b, kv head, split) slot as the workspace is SIZED: the lean kernel may run 5 .. 16 heads as ceil(G / 4) virtual kv
-// heads of ceil(G / parts) heads (attn_mfma.hip lean_virtual) - that many slots of the smaller group, each rounded up by itself
+// heads of ceil(G / parts) heads (attn_mfma.hip mfma_virtual) - that many slots of the smaller group, each rounded up by itself
 static size_t slot_floats_sized(int G, int d) {
     size_t n = slot_floats_for(G, d);
     if (G > 4 && G <= 16) {
@@ -174,7 +174,7 @@ static int fill_attn_params(const million_attn_desc *desc, AttnParams &p) {
     p.G = p.Gt < kMaxGMfma ? p.Gt : kMaxGMfma;      // in one launch, the tile / scalar kernels kMaxG = 8; bigger groups run as several
                                               // launches (attn_impl).  G = heads of one launch, sized here for the largest
     p.g0 = 0;
-    p.nhk_real = 1 << 28; p.nhk_mul = 0; p.hparts_m1 = 0; p.G_all = 0;      // no query-head parts (attn_mfma.hip lean_virtual sets them)
+    p.nhk_real = 1 << 28; p.nhk_mul = 0; p.hparts_m1 = 0; p.G_all = 0;      // no query-head parts (attn_mfma.hip mfma_virtual sets them)
     if (p.M <= 0 || p.d <= 0 || p.d % p.M || p.M % 4) { set_error("attn: d=%d M=%d", p.d, p.M); return MILLION_ERR_SHAPE; }
     p.dm = p.d / p.M;
     if (p.C < 2 || p.C > 256) { set_error("attn: C=%d (uint8 codes)", p.C); return MILLION_ERR_SHAPE; }
