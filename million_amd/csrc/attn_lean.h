@@ -118,7 +118,10 @@ __device__ __forceinline__ void lean_load_res_tile(const AttnParams &p, int bh, 
 // are (q, 0), the residual rows are read at their real length, and the accumulators - whose odd-parity rows stay zero - are
 // packed into the d = 64 layout by 8 ds_bpermute in front of the tail.  Same gathers and products per token as d = 128 / M = 64
 // (half of the score MACs multiply zeros: the matrix pipe is not what bounds this kernel).
-template <int MODE, int MS = 64, int DD = 128, int DR = DD>
+// FL: which run-time extras the instance carries (the BASELINE shapes' instances carry none: this code runs from a cold instruction
+// cache and every branch of its prologue is on the launch's critical path - 0.25 us per launch with both compiled in everywhere):
+//   1 = may be given 128 centroids (p.C): the LDS copy spreads the K rows;  2 = may run as query-head parts (AttnParams::nhk_real)
+template <int MODE, int MS = 64, int DD = 128, int DR = DD, int FL = 0>
 __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     static_assert((DD == 128 && (MS == 64 || MS == 32)) || (DD == 64 && (MS == 32 || MS == 16)), "lean kernel: d_m = 2 or 4 at d = 128 / 64");
     static_assert(DR == DD || (DR == 64 && DD == 128 && MS == 64), "lean kernel: the padded form is d = 64 / M = 64 only");
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     }
     const int b = bh / p.nh_k, hk = bh % p.nh_k;      // hk, bh: VIRTUAL when the launch splits the query heads of a kv head into parts
     // real kv head / pair (what codes, page ids, window rows and the new rows are indexed by) and this workgroup's part
-    const int part = head_part(p, hk), hkr = hk - part * p.nhk_mul;
-    const int bhr = bh - (b * p.hparts_m1 + part) * p.nhk_mul;
-    const int G = p.nhk_mul ? min(p.G, p.G_all - part * p.G) : p.G;      // (the last part of an odd head group holds fewer)
+    const int part = (FL & 2) ? head_part(p, hk) : 0, hkr = hk - part * p.nhk_mul;
+    const int bhr = (FL & 2) ? bh - (b * p.hparts_m1 + part) * p.nhk_mul : bh;
+    const int G = (FL & 2) && p.nhk_mul ? min(p.G, p.G_all - part * p.G) : p.G;      // (the last part of an odd head group holds fewer)
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
     const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;
@@ -208,20 +211,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
         new_k = *(const h2 *)(p.k_new + (long long)bhr * DR + 2 * lane);
         new_v = *(const h2 *)(p.v_new + (long long)bhr * DR + 2 * lane);
     }
-    // 128 centroids (wave-uniform): half the pieces; the K rows are spread to the 256-entry row stride the gathers use (below)
-    const bool c128 = p.C == 128;
-    const int nt_rt = c128 ? NT / 2 : NT;
+    // (128 centroids: the same loads - the second half of them reads the image that follows in the prepared buffer and is dropped
+    // by the copy into LDS below, which spreads the K rows to the 256-entry row stride the gathers use)
     v4u tabk[NT], tabv[NT];
-    const int rot = (blockIdx.x + 5 * blockIdx.y) & (nt_rt - 1);
+    const int rot = (blockIdx.x + 5 * blockIdx.y) & (NT - 1);
     {
         const v4u *ks = (const v4u *)p.k_tab;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-            if (i < nt_rt) tabk[i] = ks[((i + rot) & (nt_rt - 1)) * (kNW * 64) + tid];
+        for (int i = 0; i < NT; ++i) tabk[i] = ks[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
         const v4u *vs = (const v4u *)p.v_tab_col;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-            if (i < nt_rt) tabv[i] = vs[((i + rot) & (nt_rt - 1)) * (kNW * 64) + tid];
+        for (int i = 0; i < NT; ++i) tabv[i] = vs[((i + rot) & (NT - 1)) * (kNW * 64) + tid];
     }
     if (p.dev_lengths)
         asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dl) : "s"(p.dev_lengths), "s"((unsigned)b * 16u) : "memory");
@@ -294,14 +294,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_lean_kernel(AttnParams p) {
     {
         v4u *ld = (v4u *)smem;
         v4u *ldv = (v4u *)(smem + kVBase);
-        if (c128) {
+        if ((FL & 1) && p.C == 128) {      // (wave-uniform)
             // K row image [m][128][d_m]: row m goes to the 256-entry row stride of the C = 256 image (codes are < 128: the second half of
-            // a row is never read); V col image [c][m][d_m]: the first 128 rows, placed as for C = 256
+            // a row is never read); V col image [c][m][d_m]: the first 128 rows, placed as for C = 256.  Pieces of the images' size only
             constexpr unsigned RBS = 128u * (DR / MS) * 2u;               // source bytes of a K row
             constexpr unsigned LROW = 256u * (DD / MS) * 2u;              // its LDS stride
 #pragma unroll
-            for (int i = 0; i < NT / 2; ++i) {
-                const unsigned pi_ = ((i + rot) & (NT / 2 - 1)) * (kNW * 64) + tid;
+            for (int i = 0; i < NT; ++i) {
+                if (((i + rot) & (NT - 1)) >= NT / 2) continue;
+                const unsigned pi_ = ((i + rot) & (NT - 1)) * (kNW * 64) + tid;
                 const unsigned off = pi_ * 16u, kd = (off / RBS) * LROW + (off % RBS) * (PAD ? 2u : 1u);
                 if constexpr (PAD) {
                     *(v4u *)(smem + kd) = v4u{tabk[i][0] & 0xffffu, tabk[i][0] >> 16, tabk[i][1] & 0xffffu, tabk[i][1] >> 16};

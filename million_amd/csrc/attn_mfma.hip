@@ -1644,9 +1644,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void attn_stream_kernel(AttnParams p) 
     }
     const int b = bh / p.nh_k, hk = bh % p.nh_k;      // hk, bh: VIRTUAL when the launch splits the query heads of a kv head into parts
     // (AttnParams::nhk_real): the real kv head / pair index codes, page ids, window rows and the new rows
-    const int part = head_part(p, hk), hkr = hk - part * p.nhk_mul;
-    const int bhr = bh - (b * p.hparts_m1 + part) * p.nhk_mul;
-    const int G = p.nhk_mul ? min(p.G, p.G_all - part * p.G) : p.G;      // (the last part of an odd head group holds fewer)
+    constexpr bool PARTS = MSX == 16;      // only the d_m = 8 form runs as query-head parts: the other instances do not carry the code
+    const int part = PARTS ? head_part(p, hk) : 0, hkr = hk - part * p.nhk_mul;
+    const int bhr = PARTS ? bh - (b * p.hparts_m1 + part) * p.nhk_mul : bh;
+    const int G = PARTS && p.nhk_mul ? min(p.G, p.G_all - part * p.G) : p.G;      // (the last part of an odd head group holds fewer)
     const bool k_paged = MODE == 0 ? true : MODE == 1 ? false : (p.k_paged != 0);
     const bool v_ident = MODE == 0 ? false : MODE == 1 ? true : (p.v_identity != 0);
     const bool ids64 = MODE == 2 ? (p.ids64 != 0) : false;
@@ -2247,21 +2248,23 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<16, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<64, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_stream_kernel<32, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 64, 128, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 64, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 64, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 64, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32, 128, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 32, 64, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 32, 64, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 32, 64, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 16, 64, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 16, 64, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 16, 64, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<0, 64, 128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<1, 64, 128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void *)attn_lean_kernel<2, 64, 128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     }
     const bool stream_ok = mfma_stream_ok(p, ns);
     const int mode = (p.k_paged && !p.v_identity && !p.ids64) ? 0 : (!p.k_paged && p.v_identity) ? 1 : 2;
@@ -2269,17 +2272,17 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     if (p.d == 64) {       // lean kernel or nothing of this file (the caller's next choice: the tile kernel)
         if (!lean_takes(p_in)) return kAttnNotHandled;
         if (p.M == 64) {
-            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 64, 128, 64>), grid, block, kLdsBytes, s, p);
-            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 64, 128, 64>), grid, block, kLdsBytes, s, p);
-            else hipLaunchKernelGGL((attn_lean_kernel<2, 64, 128, 64>), grid, block, kLdsBytes, s, p);
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 64, 128, 64, 3>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 64, 128, 64, 3>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 64, 128, 64, 3>), grid, block, kLdsBytes, s, p);
         } else if (p.M == 32) {
-            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32, 64>), grid, block, kLdsBytes, s, p);
-            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32, 64>), grid, block, kLdsBytes, s, p);
-            else hipLaunchKernelGGL((attn_lean_kernel<2, 32, 64>), grid, block, kLdsBytes, s, p);
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32, 64, 64, 3>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32, 64, 64, 3>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 32, 64, 64, 3>), grid, block, kLdsBytes, s, p);
         } else {
-            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 16, 64>), grid, block, kLdsBytes, s, p);
-            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 16, 64>), grid, block, kLdsBytes, s, p);
-            else hipLaunchKernelGGL((attn_lean_kernel<2, 16, 64>), grid, block, kLdsBytes, s, p);
+            if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 16, 64, 64, 3>), grid, block, kLdsBytes, s, p);
+            else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 16, 64, 64, 3>), grid, block, kLdsBytes, s, p);
+            else hipLaunchKernelGGL((attn_lean_kernel<2, 16, 64, 64, 3>), grid, block, kLdsBytes, s, p);
         }
     } else
     if (p.M == 16) {       // d_m = 8 form: the streaming kernel or the tile kernel (the caller's next choice)
@@ -2291,11 +2294,13 @@ int launch_attn_mfma(const AttnParams &p_in, hipStream_t s) {
     } else
     // lean kernel (round 5): 64-token units, lane = token; C = 256 and (its table copy spreads the K rows) C = 128
     if (g_mfma_policy == 0 && stream_ok && p.M == 64 && p.G <= 4 && p.page_size >= 64 && !g_lean_off) {
-        if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0>), grid, block, kLdsBytes, s, p);
+        if (p.C == 128) hipLaunchKernelGGL((attn_lean_kernel<2, 64, 128, 128, 1>), grid, block, kLdsBytes, s, p);
+        else if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0>), grid, block, kLdsBytes, s, p);
         else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1>), grid, block, kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_lean_kernel<2>), grid, block, kLdsBytes, s, p);
     } else if (g_mfma_policy == 0 && stream_ok && p.M == 32 && p.G <= 4 && p.page_size >= 64 && !g_lean_off && !(g_mfma_form & 1)) {      // d_m = 4
-        if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32>), grid, block, kLdsBytes, s, p);
+        if (p.C == 128) hipLaunchKernelGGL((attn_lean_kernel<2, 32, 128, 128, 1>), grid, block, kLdsBytes, s, p);
+        else if (mode == 0) hipLaunchKernelGGL((attn_lean_kernel<0, 32>), grid, block, kLdsBytes, s, p);
         else if (mode == 1) hipLaunchKernelGGL((attn_lean_kernel<1, 32>), grid, block, kLdsBytes, s, p);
         else hipLaunchKernelGGL((attn_lean_kernel<2, 32>), grid, block, kLdsBytes, s, p);
     } else
