@@ -13,6 +13,7 @@
 //                        xor-ed into a sink instead of gathered, multiplied and soft-maxed         profiles/r04_launch_floor.txt
 //     prefill.hip     1  no exponentials, 2 no tile barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
 //                                                                                                 profiles/r03_prefill.txt, r04_prefill.txt
+//                   4 / 8 also in the pipelined kernel (no value / no score products);
 //                   256  pipelined kernel: no exponentials, 512 no tile DMA behind the prologue, 1024 no tile wait/barrier  profiles/r05_prefill.txt
 //                  2048  pipelined kernel: per-phase shader-clock sums of workgroup 0's waves, written into their own query rows (tools/prefill_prof.py)
 //                 16384  pipelined kernel: only waves 0 - 3 compute (one computing wave per SIMD; its partner issues DMA and joins barriers)

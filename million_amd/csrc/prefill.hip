@@ -515,8 +515,13 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
             pv4s lo[3], hi[3];
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
+#if MILLION_EXP & 8
+                if (s == 0) N = NEG;      // ablation: no score products (the operand reads stay: kept alive below)
+                N[s] += (float)af[s % 3][0];
+#else
                 if (s == 0) N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], NEG, 0, 0, 0);
                 else N = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % 3], qf[s], N, 0, 0, 0);
+#endif
                 PF_PIN(N);
                 if (s + 3 < DS) af[s % 3] = PF_KFRAG(HN, (s + 3) & 7);
                 else { lo[s - 5] = PF_VFRAG(BUFV, JT, 0, 0, (s - 5) & 3); hi[s - 5] = PF_VFRAG(BUFV, JT, 0, 1, (s - 5) & 3); }
@@ -542,7 +547,11 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
                 typedef short v8s __attribute__((ext_vector_type(8)));
                 const v8s av = {lo[i % 3][0], lo[i % 3][1], lo[i % 3][2], lo[i % 3][3], hi[i % 3][0], hi[i % 3][1], hi[i % 3][2], hi[i % 3][3]};
                 const pv4u pwv = {pw8[4 * ks], pw8[4 * ks + 1], pw8[4 * ks + 2], pw8[4 * ks + 3]};
+#if MILLION_EXP & 4
+                O[blk][i] += __builtin_bit_cast(float, ((unsigned)(unsigned short)av[0] | pwv[0]) & 1u);      // ablation: no value products
+#else
                 O[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, av), __builtin_bit_cast(v8h, pwv), O[blk], 0, 0, 0);
+#endif
                 PF_PIN(O[blk]);
                 if (i + 3 < 8) { lo[i % 3] = PF_VFRAG(BUFV, JT, ((i + 3) >> 2) & 1, 0, (i + 3) & 3); hi[i % 3] = PF_VFRAG(BUFV, JT, ((i + 3) >> 2) & 1, 1, (i + 3) & 3); }
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(N[2 * i]), "v"(N[2 * i + 1]));
