@@ -235,7 +235,7 @@ const char *million_last_error(void) { return g_err; }
 void million_set_force_generic(int on) {
     g_force_generic = (on == 1);
     million::set_mfma_policy(on == 2 ? 1 : on == 4 ? 2 : on == 8 ? 4 : on == 16 ? 8 : 0);
-    million::set_prefill_policy(on == 64 ? 1 : 0);
+    million::set_prefill_policy(on == 64 ? 1 : on == 128 ? 2 : 0);      // (128: a development build's experimental form; the product build ignores it)
 }
 void million_debug_set_stamp_buffer(void *buf) { g_dbg = (unsigned long long *)buf; }
 

@@ -31,6 +31,7 @@
 
 #include "common.h"
 
+#include <utility>
 #include "dev_switches.h"  // MILLION_EXP: development ablation switches (tools/ab_build.py, tools/pf_ab.sh); 0 in the product build:
                            // 1 no exponentials, 2 no barrier, 4 no PV MFMAs, 8 no QK MFMAs, 16 no global -> LDS staging
 
@@ -616,6 +617,384 @@ __global__ __launch_bounds__(8 * 64, 2) void prefill_attn_pipe_kernel(PrefillPar
 }
 #undef PF_PIN
 
+#ifdef MILLION_DEV_BUILD
+// =====================================================================================================
+// Experiment (development builds only; million_set_force_generic(128)): the pipelined kernel with FOUR waves of 64 query rows - one wave
+// per SIMD, two 32-row blocks per wave sharing every K / V operand read (half the LDS reads per product), two independent chains for
+// the in-order wave to interleave.  Same tiles, LDS image, DMA stream, numerics.  profiles/r05_prefill.txt section 10.
+// =====================================================================================================
+template <class F, int... I> __device__ __forceinline__ void w64_sfor_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void w64_sfor(F &&f) { w64_sfor_impl(f, std::make_integer_sequence<int, N>{}); }      // f(integral_constant<int, 0>) .. f(<N - 1>)
+// Accumulator-file registers OWNED by the asm of prefill_attn_w64_kernel (named literally, listed as clobbers where written; the compiler
+// never allocates AGPRs of its own there - audited in the .s: no v_accvgpr_* outside ;;#ASMSTART / ;;#ASMEND):
+//   a[16 K .. 16 K + 15], K = 4 j + blk < 8: the output tile O[j][blk];   a[128 + 4 Q .. + 3], Q = 8 j + s < 16: the query operand qf[j][s]
+__device__ __forceinline__ void w64_o_zero() { asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\tv_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\tv_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\tv_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); }
+template <int Q> __device__ __forceinline__ void w64_q_store(pv4u w) {
+    if constexpr (Q == 0) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a128, %0\n\tv_accvgpr_write_b32 a129, %1\n\tv_accvgpr_write_b32 a130, %2\n\tv_accvgpr_write_b32 a131, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a128", "a129", "a130", "a131");
+    else if constexpr (Q == 1) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a132, %0\n\tv_accvgpr_write_b32 a133, %1\n\tv_accvgpr_write_b32 a134, %2\n\tv_accvgpr_write_b32 a135, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a132", "a133", "a134", "a135");
+    else if constexpr (Q == 2) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a136, %0\n\tv_accvgpr_write_b32 a137, %1\n\tv_accvgpr_write_b32 a138, %2\n\tv_accvgpr_write_b32 a139, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a136", "a137", "a138", "a139");
+    else if constexpr (Q == 3) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a140, %0\n\tv_accvgpr_write_b32 a141, %1\n\tv_accvgpr_write_b32 a142, %2\n\tv_accvgpr_write_b32 a143, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a140", "a141", "a142", "a143");
+    else if constexpr (Q == 4) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a144, %0\n\tv_accvgpr_write_b32 a145, %1\n\tv_accvgpr_write_b32 a146, %2\n\tv_accvgpr_write_b32 a147, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a144", "a145", "a146", "a147");
+    else if constexpr (Q == 5) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a148, %0\n\tv_accvgpr_write_b32 a149, %1\n\tv_accvgpr_write_b32 a150, %2\n\tv_accvgpr_write_b32 a151, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a148", "a149", "a150", "a151");
+    else if constexpr (Q == 6) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a152, %0\n\tv_accvgpr_write_b32 a153, %1\n\tv_accvgpr_write_b32 a154, %2\n\tv_accvgpr_write_b32 a155, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a152", "a153", "a154", "a155");
+    else if constexpr (Q == 7) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a156, %0\n\tv_accvgpr_write_b32 a157, %1\n\tv_accvgpr_write_b32 a158, %2\n\tv_accvgpr_write_b32 a159, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a156", "a157", "a158", "a159");
+    else if constexpr (Q == 8) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a160, %0\n\tv_accvgpr_write_b32 a161, %1\n\tv_accvgpr_write_b32 a162, %2\n\tv_accvgpr_write_b32 a163, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a160", "a161", "a162", "a163");
+    else if constexpr (Q == 9) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a164, %0\n\tv_accvgpr_write_b32 a165, %1\n\tv_accvgpr_write_b32 a166, %2\n\tv_accvgpr_write_b32 a167, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a164", "a165", "a166", "a167");
+    else if constexpr (Q == 10) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a168, %0\n\tv_accvgpr_write_b32 a169, %1\n\tv_accvgpr_write_b32 a170, %2\n\tv_accvgpr_write_b32 a171, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a168", "a169", "a170", "a171");
+    else if constexpr (Q == 11) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a172, %0\n\tv_accvgpr_write_b32 a173, %1\n\tv_accvgpr_write_b32 a174, %2\n\tv_accvgpr_write_b32 a175, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a172", "a173", "a174", "a175");
+    else if constexpr (Q == 12) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a176, %0\n\tv_accvgpr_write_b32 a177, %1\n\tv_accvgpr_write_b32 a178, %2\n\tv_accvgpr_write_b32 a179, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a176", "a177", "a178", "a179");
+    else if constexpr (Q == 13) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a180, %0\n\tv_accvgpr_write_b32 a181, %1\n\tv_accvgpr_write_b32 a182, %2\n\tv_accvgpr_write_b32 a183, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a180", "a181", "a182", "a183");
+    else if constexpr (Q == 14) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a184, %0\n\tv_accvgpr_write_b32 a185, %1\n\tv_accvgpr_write_b32 a186, %2\n\tv_accvgpr_write_b32 a187, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a184", "a185", "a186", "a187");
+    else if constexpr (Q == 15) asm volatile("s_nop 0\n\tv_accvgpr_write_b32 a188, %0\n\tv_accvgpr_write_b32 a189, %1\n\tv_accvgpr_write_b32 a190, %2\n\tv_accvgpr_write_b32 a191, %3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]) : "a188", "a189", "a190", "a191");
+}
+template <int Q, bool FIRST> __device__ __forceinline__ void w64_qk(v16f &N, v8h af, const v16f &NEG) {
+    if constexpr (Q == 0) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[128:131], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[128:131], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 1) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[132:135], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[132:135], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 2) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[136:139], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[136:139], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 3) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[140:143], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[140:143], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 4) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[144:147], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[144:147], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 5) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[148:151], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[148:151], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 6) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[152:155], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[152:155], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 7) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[156:159], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[156:159], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 8) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[160:163], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[160:163], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 9) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[164:167], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[164:167], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 10) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[168:171], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[168:171], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 11) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[172:175], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[172:175], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 12) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[176:179], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[176:179], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 13) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[180:183], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[180:183], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 14) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[184:187], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[184:187], %0" : "+v"(N) : "v"(af)); }
+    else if constexpr (Q == 15) { if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[188:191], %2" : "=&v"(N) : "v"(af), "v"(NEG)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[188:191], %0" : "+v"(N) : "v"(af)); }
+}
+template <int K> __device__ __forceinline__ void w64_pv(v8h av, v8h pw) {
+    if constexpr (K == 0) asm volatile("v_mfma_f32_32x32x16_f16 a[0:15], %0, %1, a[0:15]" :: "v"(av), "v"(pw) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    else if constexpr (K == 1) asm volatile("v_mfma_f32_32x32x16_f16 a[16:31], %0, %1, a[16:31]" :: "v"(av), "v"(pw) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    else if constexpr (K == 2) asm volatile("v_mfma_f32_32x32x16_f16 a[32:47], %0, %1, a[32:47]" :: "v"(av), "v"(pw) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    else if constexpr (K == 3) asm volatile("v_mfma_f32_32x32x16_f16 a[48:63], %0, %1, a[48:63]" :: "v"(av), "v"(pw) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    else if constexpr (K == 4) asm volatile("v_mfma_f32_32x32x16_f16 a[64:79], %0, %1, a[64:79]" :: "v"(av), "v"(pw) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    else if constexpr (K == 5) asm volatile("v_mfma_f32_32x32x16_f16 a[80:95], %0, %1, a[80:95]" :: "v"(av), "v"(pw) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    else if constexpr (K == 6) asm volatile("v_mfma_f32_32x32x16_f16 a[96:111], %0, %1, a[96:111]" :: "v"(av), "v"(pw) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    else if constexpr (K == 7) asm volatile("v_mfma_f32_32x32x16_f16 a[112:127], %0, %1, a[112:127]" :: "v"(av), "v"(pw) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+}
+template <int K> __device__ __forceinline__ void w64_o_scale(float alpha) {      // O[K] *= alpha (the caller has waited for the products that wrote it)
+    float t_;
+    if constexpr (K == 0) asm volatile("v_accvgpr_read_b32 %0, a0\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a0, %0\n\tv_accvgpr_read_b32 %0, a1\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a1, %0\n\tv_accvgpr_read_b32 %0, a2\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a2, %0\n\tv_accvgpr_read_b32 %0, a3\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a3, %0\n\tv_accvgpr_read_b32 %0, a4\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a4, %0\n\tv_accvgpr_read_b32 %0, a5\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a5, %0\n\tv_accvgpr_read_b32 %0, a6\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a6, %0\n\tv_accvgpr_read_b32 %0, a7\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a7, %0\n\tv_accvgpr_read_b32 %0, a8\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a8, %0\n\tv_accvgpr_read_b32 %0, a9\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a9, %0\n\tv_accvgpr_read_b32 %0, a10\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a10, %0\n\tv_accvgpr_read_b32 %0, a11\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a11, %0\n\tv_accvgpr_read_b32 %0, a12\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a12, %0\n\tv_accvgpr_read_b32 %0, a13\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a13, %0\n\tv_accvgpr_read_b32 %0, a14\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a14, %0\n\tv_accvgpr_read_b32 %0, a15\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a15, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    else if constexpr (K == 1) asm volatile("v_accvgpr_read_b32 %0, a16\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a16, %0\n\tv_accvgpr_read_b32 %0, a17\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a17, %0\n\tv_accvgpr_read_b32 %0, a18\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a18, %0\n\tv_accvgpr_read_b32 %0, a19\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a19, %0\n\tv_accvgpr_read_b32 %0, a20\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a20, %0\n\tv_accvgpr_read_b32 %0, a21\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a21, %0\n\tv_accvgpr_read_b32 %0, a22\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a22, %0\n\tv_accvgpr_read_b32 %0, a23\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a23, %0\n\tv_accvgpr_read_b32 %0, a24\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a24, %0\n\tv_accvgpr_read_b32 %0, a25\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a25, %0\n\tv_accvgpr_read_b32 %0, a26\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a26, %0\n\tv_accvgpr_read_b32 %0, a27\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a27, %0\n\tv_accvgpr_read_b32 %0, a28\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a28, %0\n\tv_accvgpr_read_b32 %0, a29\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a29, %0\n\tv_accvgpr_read_b32 %0, a30\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a30, %0\n\tv_accvgpr_read_b32 %0, a31\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a31, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    else if constexpr (K == 2) asm volatile("v_accvgpr_read_b32 %0, a32\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a32, %0\n\tv_accvgpr_read_b32 %0, a33\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a33, %0\n\tv_accvgpr_read_b32 %0, a34\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a34, %0\n\tv_accvgpr_read_b32 %0, a35\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a35, %0\n\tv_accvgpr_read_b32 %0, a36\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a36, %0\n\tv_accvgpr_read_b32 %0, a37\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a37, %0\n\tv_accvgpr_read_b32 %0, a38\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a38, %0\n\tv_accvgpr_read_b32 %0, a39\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a39, %0\n\tv_accvgpr_read_b32 %0, a40\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a40, %0\n\tv_accvgpr_read_b32 %0, a41\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a41, %0\n\tv_accvgpr_read_b32 %0, a42\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a42, %0\n\tv_accvgpr_read_b32 %0, a43\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a43, %0\n\tv_accvgpr_read_b32 %0, a44\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a44, %0\n\tv_accvgpr_read_b32 %0, a45\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a45, %0\n\tv_accvgpr_read_b32 %0, a46\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a46, %0\n\tv_accvgpr_read_b32 %0, a47\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a47, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    else if constexpr (K == 3) asm volatile("v_accvgpr_read_b32 %0, a48\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a48, %0\n\tv_accvgpr_read_b32 %0, a49\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a49, %0\n\tv_accvgpr_read_b32 %0, a50\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a50, %0\n\tv_accvgpr_read_b32 %0, a51\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a51, %0\n\tv_accvgpr_read_b32 %0, a52\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a52, %0\n\tv_accvgpr_read_b32 %0, a53\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a53, %0\n\tv_accvgpr_read_b32 %0, a54\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a54, %0\n\tv_accvgpr_read_b32 %0, a55\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a55, %0\n\tv_accvgpr_read_b32 %0, a56\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a56, %0\n\tv_accvgpr_read_b32 %0, a57\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a57, %0\n\tv_accvgpr_read_b32 %0, a58\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a58, %0\n\tv_accvgpr_read_b32 %0, a59\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a59, %0\n\tv_accvgpr_read_b32 %0, a60\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a60, %0\n\tv_accvgpr_read_b32 %0, a61\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a61, %0\n\tv_accvgpr_read_b32 %0, a62\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a62, %0\n\tv_accvgpr_read_b32 %0, a63\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a63, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    else if constexpr (K == 4) asm volatile("v_accvgpr_read_b32 %0, a64\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a64, %0\n\tv_accvgpr_read_b32 %0, a65\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a65, %0\n\tv_accvgpr_read_b32 %0, a66\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a66, %0\n\tv_accvgpr_read_b32 %0, a67\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a67, %0\n\tv_accvgpr_read_b32 %0, a68\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a68, %0\n\tv_accvgpr_read_b32 %0, a69\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a69, %0\n\tv_accvgpr_read_b32 %0, a70\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a70, %0\n\tv_accvgpr_read_b32 %0, a71\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a71, %0\n\tv_accvgpr_read_b32 %0, a72\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a72, %0\n\tv_accvgpr_read_b32 %0, a73\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a73, %0\n\tv_accvgpr_read_b32 %0, a74\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a74, %0\n\tv_accvgpr_read_b32 %0, a75\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a75, %0\n\tv_accvgpr_read_b32 %0, a76\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a76, %0\n\tv_accvgpr_read_b32 %0, a77\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a77, %0\n\tv_accvgpr_read_b32 %0, a78\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a78, %0\n\tv_accvgpr_read_b32 %0, a79\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a79, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    else if constexpr (K == 5) asm volatile("v_accvgpr_read_b32 %0, a80\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a80, %0\n\tv_accvgpr_read_b32 %0, a81\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a81, %0\n\tv_accvgpr_read_b32 %0, a82\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a82, %0\n\tv_accvgpr_read_b32 %0, a83\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a83, %0\n\tv_accvgpr_read_b32 %0, a84\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a84, %0\n\tv_accvgpr_read_b32 %0, a85\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a85, %0\n\tv_accvgpr_read_b32 %0, a86\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a86, %0\n\tv_accvgpr_read_b32 %0, a87\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a87, %0\n\tv_accvgpr_read_b32 %0, a88\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a88, %0\n\tv_accvgpr_read_b32 %0, a89\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a89, %0\n\tv_accvgpr_read_b32 %0, a90\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a90, %0\n\tv_accvgpr_read_b32 %0, a91\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a91, %0\n\tv_accvgpr_read_b32 %0, a92\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a92, %0\n\tv_accvgpr_read_b32 %0, a93\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a93, %0\n\tv_accvgpr_read_b32 %0, a94\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a94, %0\n\tv_accvgpr_read_b32 %0, a95\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a95, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    else if constexpr (K == 6) asm volatile("v_accvgpr_read_b32 %0, a96\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a96, %0\n\tv_accvgpr_read_b32 %0, a97\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a97, %0\n\tv_accvgpr_read_b32 %0, a98\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a98, %0\n\tv_accvgpr_read_b32 %0, a99\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a99, %0\n\tv_accvgpr_read_b32 %0, a100\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a100, %0\n\tv_accvgpr_read_b32 %0, a101\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a101, %0\n\tv_accvgpr_read_b32 %0, a102\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a102, %0\n\tv_accvgpr_read_b32 %0, a103\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a103, %0\n\tv_accvgpr_read_b32 %0, a104\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a104, %0\n\tv_accvgpr_read_b32 %0, a105\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a105, %0\n\tv_accvgpr_read_b32 %0, a106\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a106, %0\n\tv_accvgpr_read_b32 %0, a107\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a107, %0\n\tv_accvgpr_read_b32 %0, a108\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a108, %0\n\tv_accvgpr_read_b32 %0, a109\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a109, %0\n\tv_accvgpr_read_b32 %0, a110\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a110, %0\n\tv_accvgpr_read_b32 %0, a111\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a111, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    else if constexpr (K == 7) asm volatile("v_accvgpr_read_b32 %0, a112\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a112, %0\n\tv_accvgpr_read_b32 %0, a113\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a113, %0\n\tv_accvgpr_read_b32 %0, a114\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a114, %0\n\tv_accvgpr_read_b32 %0, a115\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a115, %0\n\tv_accvgpr_read_b32 %0, a116\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a116, %0\n\tv_accvgpr_read_b32 %0, a117\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a117, %0\n\tv_accvgpr_read_b32 %0, a118\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a118, %0\n\tv_accvgpr_read_b32 %0, a119\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a119, %0\n\tv_accvgpr_read_b32 %0, a120\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a120, %0\n\tv_accvgpr_read_b32 %0, a121\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a121, %0\n\tv_accvgpr_read_b32 %0, a122\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a122, %0\n\tv_accvgpr_read_b32 %0, a123\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a123, %0\n\tv_accvgpr_read_b32 %0, a124\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a124, %0\n\tv_accvgpr_read_b32 %0, a125\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a125, %0\n\tv_accvgpr_read_b32 %0, a126\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a126, %0\n\tv_accvgpr_read_b32 %0, a127\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a127, %0\n\ts_nop 1" : "=&v"(t_) : "v"(alpha) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+}
+template <int K> __device__ __forceinline__ v16f w64_o_read() {
+    float e_[16];
+    if constexpr (K == 0) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 1) asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 2) asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 3) asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\tv_accvgpr_read_b32 %8, a56\n\tv_accvgpr_read_b32 %9, a57\n\tv_accvgpr_read_b32 %10, a58\n\tv_accvgpr_read_b32 %11, a59\n\tv_accvgpr_read_b32 %12, a60\n\tv_accvgpr_read_b32 %13, a61\n\tv_accvgpr_read_b32 %14, a62\n\tv_accvgpr_read_b32 %15, a63\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 4) asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\tv_accvgpr_read_b32 %8, a72\n\tv_accvgpr_read_b32 %9, a73\n\tv_accvgpr_read_b32 %10, a74\n\tv_accvgpr_read_b32 %11, a75\n\tv_accvgpr_read_b32 %12, a76\n\tv_accvgpr_read_b32 %13, a77\n\tv_accvgpr_read_b32 %14, a78\n\tv_accvgpr_read_b32 %15, a79\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 5) asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\tv_accvgpr_read_b32 %8, a88\n\tv_accvgpr_read_b32 %9, a89\n\tv_accvgpr_read_b32 %10, a90\n\tv_accvgpr_read_b32 %11, a91\n\tv_accvgpr_read_b32 %12, a92\n\tv_accvgpr_read_b32 %13, a93\n\tv_accvgpr_read_b32 %14, a94\n\tv_accvgpr_read_b32 %15, a95\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 6) asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\tv_accvgpr_read_b32 %8, a104\n\tv_accvgpr_read_b32 %9, a105\n\tv_accvgpr_read_b32 %10, a106\n\tv_accvgpr_read_b32 %11, a107\n\tv_accvgpr_read_b32 %12, a108\n\tv_accvgpr_read_b32 %13, a109\n\tv_accvgpr_read_b32 %14, a110\n\tv_accvgpr_read_b32 %15, a111\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    else if constexpr (K == 7) asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a120\n\tv_accvgpr_read_b32 %9, a121\n\tv_accvgpr_read_b32 %10, a122\n\tv_accvgpr_read_b32 %11, a123\n\tv_accvgpr_read_b32 %12, a124\n\tv_accvgpr_read_b32 %13, a125\n\tv_accvgpr_read_b32 %14, a126\n\tv_accvgpr_read_b32 %15, a127\n\ts_nop 0" : "=v"(e_[0]), "=v"(e_[1]), "=v"(e_[2]), "=v"(e_[3]), "=v"(e_[4]), "=v"(e_[5]), "=v"(e_[6]), "=v"(e_[7]), "=v"(e_[8]), "=v"(e_[9]), "=v"(e_[10]), "=v"(e_[11]), "=v"(e_[12]), "=v"(e_[13]), "=v"(e_[14]), "=v"(e_[15]));
+    v16f r_;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r_[e] = e_[e];
+    return r_;
+}
+__global__ __launch_bounds__(4 * 64, 1) void prefill_attn_w64_kernel(PrefillParams p) {
+    constexpr int D = 128, kPW = 4, NQ = 2, DS = D / 16, NB = D / 32, kTileBytes = kKV * 2 * D;
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_smem != 0u) __builtin_trap();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    int id = blockIdx.x;
+    const int hk = id % p.nh_k;
+    id /= p.nh_k;
+    const int n_hg = p.G / p.hpw;
+    const int hg = id % n_hg;
+    id /= n_hg;
+    const int qb = p.n_qb - 1 - id % p.n_qb;
+    const int b = id / p.n_qb;
+    const int wph = kPW / p.hpw;                  // waves per head (hpw <= 4 here)
+    const int QB = wph * 64;
+    const int g = hg * p.hpw + wave / wph;
+    const int head = hk * p.G + g;
+    const int q_lo = qb * QB + (wave % wph) * 64;
+    auto q_all = [&](auto jc, auto sc, const f16 *qp) {
+        constexpr int J = decltype(jc)::value, S = decltype(sc)::value;
+        v8h t = *(const v8h *)(qp + 16 * S);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (f16)((float)t[e] * p.scale_log2e);
+        w64_q_store<8 * J + S>(__builtin_bit_cast(pv4u, t));
+    };
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q_row = q_lo + 32 * j + r32;
+        const int qr = q_row < p.n_q ? q_row : p.n_q - 1;
+        const f16 *qp = p.q + b * p.q_sb + head * p.q_sh + (long long)qr * p.q_sn + 8 * hh;
+        if (j == 0) { q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, qp); q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, qp); q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, qp); q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, qp);
+                      q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, qp); q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, qp); q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, qp); q_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{}, qp); }
+        else        { q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, qp); q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, qp); q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, qp); q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, qp);
+                      q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, qp); q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 5>{}, qp); q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 6>{}, qp); q_all(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{}, qp); }
+    }
+    const int wg_q_hi = qb * QB + QB - 1 < p.n_q - 1 ? qb * QB + QB - 1 : p.n_q - 1;
+    int kv_end_wg = p.causal ? p.q_pos0 + wg_q_hi + 1 : p.n_kv;
+    kv_end_wg = kv_end_wg < p.n_kv ? kv_end_wg : p.n_kv;
+    const int nt = kv_end_wg > 0 ? (kv_end_wg + kKV - 1) / kKV : 0;
+    const int nh2 = 2 * nt;
+    const int w_pos_hi = p.q_pos0 + q_lo + 63;
+    const bool wave_live = q_lo < p.n_q;
+    const f16 *kbase = p.k + b * p.k_sb + hk * p.k_sh;
+    const f16 *vbase = p.v + b * p.v_sb + hk * p.v_sh;
+    // one-KiB pieces: piece wave + 4 i, i < 4: a K half = pieces 8 jt .. 8 jt + 7: two per wave (i = 2 jt, 2 jt + 1); a V tile = 16: four per wave
+    int prow[4], pch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = 64 * (wave + kPW * i) + lane;
+        prow[i] = pos >> 4;
+        pch[i] = (pos & 15) ^ (((prow[i] & 3) << 2) | ((prow[i] >> 2) & 3));
+    }
+    auto dma_piece = [&](int t, int i, bool is_v) {
+        int kvr = t * kKV + prow[i];
+        kvr = kvr < p.n_kv ? kvr : p.n_kv - 1;
+        const f16 *src = (is_v ? vbase + (long long)kvr * p.v_sn : kbase + (long long)kvr * p.k_sn) + 8 * pch[i];
+        const unsigned dst = 2u * kTileBytes * (t & 1) + (is_v ? kTileBytes : 0) + 1024u * (wave + kPW * i);
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+    };
+    auto dma_k_half = [&](int h) { if (h < nh2) { dma_piece(h >> 1, 2 * (h & 1), false); dma_piece(h >> 1, 2 * (h & 1) + 1, false); } };
+    auto dma_v_tile = [&](int t) { if (t < nt) { dma_piece(t, 0, true); dma_piece(t, 1, true); dma_piece(t, 2, true); dma_piece(t, 3, true); } };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // The products are inline asm on asm-owned accumulator registers (helpers above): hipcc left to itself moved ~570 registers per 16
+    // products between the two halves of the register file; with "+a" / "a" constraints still 128.  Wait states are ours
+    // (cdna_hip_programming.md 5.7 item 2): s_nop 1 opens every product; a score tile is read by vector code only behind W64_D_WAIT.
+#define W64_D_WAIT() asm volatile("s_nop 7\n\ts_nop 7" ::: "memory")
+    w64_o_zero();
+    float m_ref[NQ], neg_ref[NQ], thr_rel[NQ], l_run[NQ];
+    v16f NEG[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        m_ref[j] = -INFINITY; neg_ref[j] = 0.f; thr_rel[j] = -INFINITY; l_run[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) NEG[j][e] = 0.f;
+    }
+    const int qd = (lane >> 2) & 3, pp = lane & 3, g16 = (lane >> 4) & 1;
+    auto live = [&](int h) { return h < nh2 && wave_live && (!p.causal || 32 * h <= w_pos_hi); };
+    auto masked = [&](int h) { return (p.causal && 32 * h + 31 > p.q_pos0 + q_lo) || 32 * h + 32 > p.n_kv; };      // some row of the wave does not see the whole half
+    auto mask_half = [&](int h, int j, v16f &S) {
+        const int q_pos = p.q_pos0 + q_lo + 32 * j + r32;
+        const int lim = p.causal ? (q_pos < p.n_kv - 1 ? q_pos : p.n_kv - 1) : p.n_kv - 1;
+        const int rel = lim - 32 * h - 4 * hh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = (e & 3) + 8 * (e >> 2) <= rel ? S[e] : -INFINITY;
+    };
+    auto decide = [&](auto jc, float mx, v16f &Nx) {
+        constexpr int j = decltype(jc)::value;
+        {
+            const v2u ex = swap32_self(__float_as_uint(mx));
+            const unsigned e0 = ex[0], e1 = ex[1];
+            mx = fmaxf(__uint_as_float(e0), __uint_as_float(e1));
+        }
+        if (__any(mx > thr_rel[j])) {
+            const float m_new = fmaxf(m_ref[j], mx - neg_ref[j]);
+            const float m_safe = m_new > -INFINITY ? m_new : 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(m_ref[j] - m_safe);
+            W64_D_WAIT();      // (the value products that wrote O may be in flight)
+            w64_sfor<NB>([&](auto ic) { w64_o_scale<4 * j + decltype(ic)::value>(alpha); });
+            l_run[j] *= alpha;
+            m_ref[j] = m_new;
+            const float shift = -m_safe - neg_ref[j];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { Nx[e] += shift; NEG[j][e] = -m_safe; }
+            neg_ref[j] = -m_safe;
+            thr_rel[j] = 8.0f;
+        }
+    };
+    unsigned ka[DS], va[2][NB];
+    {
+        const unsigned X = ((r32 & 3) << 2) | ((r32 >> 2) & 3);
+#pragma unroll
+        for (int s_ = 0; s_ < DS; ++s_) ka[s_] = 256u * r32 + 16u * ((2u * s_ + hh) ^ X);
+#pragma unroll
+        for (int hi_ = 0; hi_ < 2; ++hi_)
+#pragma unroll
+            for (int blk_ = 0; blk_ < NB; ++blk_)
+                va[hi_][blk_] = 256u * (8 * hi_ + 4 * hh + qd) + 16u * ((((unsigned)blk_ ^ qd) << 2) | ((2u * g16 + (pp >> 1)) ^ (2u * hi_ + hh))) + 8u * (pp & 1);
+    }
+#define PF_PIN(x) asm volatile("" : "+v"(x))
+#define PF_KFRAG(HQ, S) __builtin_bit_cast(v8h, ((lds_v4u_p)(size_t)ka[S])[(2u * kTileBytes * ((HQ) >> 1) + 256u * 32u * ((HQ) & 1)) / 16])
+#define PF_VFRAG(BUFV, JT, KS, HI, BLK) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(size_t)va[HI][BLK] + (2u * kTileBytes * (BUFV) + kTileBytes + 256u * (32u * (JT) + 16u * (KS))) / 8)
+#if MILLION_EXP & 2048
+    unsigned long long pt_last = __builtin_readcyclecounter();
+    unsigned pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PT(I) { const unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[I] += (unsigned)(n_ - pt_last); pt_last = n_; }
+#else
+#define PT(I)
+#endif
+    dma_k_half(0); dma_k_half(1); dma_k_half(2); dma_v_tile(0);
+    dma_wait();
+    __syncthreads();
+    v16f SA[NQ], SB[NQ];
+    bool cur_live = live(0);
+    if (cur_live) {
+        w64_sfor<NQ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            w64_sfor<DS>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                const v8h kf = PF_KFRAG(0, s_);
+                w64_qk<8 * j + s_, s_ == 0>(SA[j], kf, NEG[j]);
+            });
+            W64_D_WAIT();
+            if (masked(0)) mask_half(0, j, SA[j]);
+            float mx = SA[j][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, SA[j][e]);
+            decide(jc, mx, SA[j]);
+        });
+    }
+    auto dma_k_half_piece = [&](int h, int jj) { if (h < nh2) dma_piece(h >> 1, 2 * (h & 1) + jj, false); };
+    v8h af[3];      // K operands in flight across a phase (and across the two half-steps of an iteration)
+    auto half_step = [&](auto hqc, v16f (&C)[NQ], v16f (&N)[NQ], const int h, const int t_dma) {
+        constexpr int HQ = decltype(hqc)::value, HN = (HQ + 1) & 3, BUFV = HQ >> 1, JT = HQ & 1;
+        const bool nxt_live = live(h + 1);
+        if (cur_live) {
+            float ls[NQ] = {0.f, 0.f}, ls2[NQ] = {0.f, 0.f}, ex[NQ][2] = {{0.f, 0.f}, {0.f, 0.f}}, mx[NQ] = {-INFINITY, -INFINITY};
+            pv4u pwq[NQ][2];      // the packed probabilities as the value products' operand tuples (written in place: no moves in front of a product)
+            if constexpr ((HQ & 1) == 0) { af[0] = PF_KFRAG(HN, 0); af[1] = PF_KFRAG(HN, 1); af[2] = PF_KFRAG(HN, 2); }
+            pv4s lo[3], hi[3];
+            w64_sfor<DS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                w64_sfor<NQ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    w64_qk<8 * j + s, s == 0>(N[j], af[s % 3], NEG[j]);
+                    if constexpr (j == NQ - 1) {
+                        if constexpr (s + 3 < DS) af[s % 3] = PF_KFRAG(HN, (s + 3) & 7);
+                        else { lo[s - 5] = PF_VFRAG(BUFV, JT, 0, 0, (s - 5) & 3); hi[s - 5] = PF_VFRAG(BUFV, JT, 0, 1, (s - 5) & 3); }
+                    }
+                    // one wave per SIMD: nothing else fills an exponential's latency, so a gap consumes the pair issued in the PREVIOUS gap
+                    // (the next pair is issued first) and the two row sums of a block run as separate chains
+                    if constexpr (s == 0) { ex[j][0] = __builtin_amdgcn_exp2f(C[j][0]); ex[j][1] = __builtin_amdgcn_exp2f(C[j][1]); }
+                    const float p0 = ex[j][0], p1 = ex[j][1];
+                    if constexpr (s + 1 < DS) { ex[j][0] = __builtin_amdgcn_exp2f(C[j][2 * s + 2]); ex[j][1] = __builtin_amdgcn_exp2f(C[j][2 * s + 3]); }
+                    ls[j] += p0;
+                    ls2[j] += p1;
+                    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                    const h2v t2 = {(f16)p0, (f16)p1};
+                    {
+                        unsigned pw_ = __builtin_bit_cast(unsigned, t2);
+                        float ls_ = ls[j], ls2_ = ls2[j], e0_ = ex[j][0], e1_ = ex[j][1];
+                        asm volatile("" : "+v"(pw_), "+v"(ls_), "+v"(ls2_), "+v"(e0_), "+v"(e1_));
+                        pwq[j][s >> 2][s & 3] = pw_;
+                        ls[j] = ls_; ls2[j] = ls2_; ex[j][0] = e0_; ex[j][1] = e1_;
+                    }
+                });
+            });
+            PT(1)
+            if (!nxt_live || masked(h + 1)) {
+                W64_D_WAIT();
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) mask_half(h + 1, j, N[j]);
+            }
+            PT(2)
+            w64_sfor<8>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, ks = i >> 2, blk = i & 3;
+                typedef short v8s __attribute__((ext_vector_type(8)));
+                const v8s av = {lo[i % 3][0], lo[i % 3][1], lo[i % 3][2], lo[i % 3][3], hi[i % 3][0], hi[i % 3][1], hi[i % 3][2], hi[i % 3][3]};
+                w64_sfor<NQ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    w64_pv<4 * j + blk>(__builtin_bit_cast(v8h, av), __builtin_bit_cast(v8h, pwq[j][ks]));
+                });
+                if constexpr (i + 3 < 8) { lo[i % 3] = PF_VFRAG(BUFV, JT, ((i + 3) >> 2) & 1, 0, (i + 3) & 3); hi[i % 3] = PF_VFRAG(BUFV, JT, ((i + 3) >> 2) & 1, 1, (i + 3) & 3); }
+                else if constexpr ((HQ & 1) == 0) af[i - 5] = PF_KFRAG((HN + 1) & 3, i - 5);      // the next half-step's first K operands (same iteration)
+                // this iteration's DMA pieces ride in the value phase's gaps (one wave per SIMD: a burst of eight at the barrier idles the matrix pipe)
+                if (t_dma >= 0) {
+                    if constexpr ((HQ & 1) == 0) { if (i == 1) dma_k_half_piece(2 * t_dma + 3, 0); if (i == 3) dma_k_half_piece(2 * t_dma + 3, 1); if (i == 5) dma_k_half_piece(2 * t_dma + 4, 0); if (i == 7) dma_k_half_piece(2 * t_dma + 4, 1); }
+                    else if (t_dma + 1 < nt) { if (i == 0) dma_piece(t_dma + 1, 0, true); if (i == 1) dma_piece(t_dma + 1, 1, true); if (i == 2) dma_piece(t_dma + 1, 2, true); if (i == 3) dma_piece(t_dma + 1, 3, true); }
+                }
+                if constexpr (i == 0) asm volatile("s_nop 3");      // (the last score products are two value products back: padded to 12 states and more)
+                w64_sfor<NQ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    {      // (locals: clang refuses asm operands that name a variable of an enclosing lambda)
+                        float m_ = mx[j];
+                        const float n0_ = N[j][2 * i], n1_ = N[j][2 * i + 1];
+                        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m_) : "v"(m_), "v"(n0_), "v"(n1_));
+                        mx[j] = m_;
+                    }
+                });
+            });
+            PT(3)
+            w64_sfor<NQ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                l_run[j] += ls[j] + ls2[j];
+                decide(jc, mx[j], N[j]);
+            });
+            PT(4)
+        } else if (t_dma >= 0) {      // a wave with nothing to compute still owns its share of the tile
+            if constexpr ((HQ & 1) == 0) { dma_k_half(2 * t_dma + 3); dma_k_half(2 * t_dma + 4); }
+            else dma_v_tile(t_dma + 1);
+        }
+        cur_live = nxt_live;
+    };
+    PT(7)
+    for (int t = 0; t < nt; t += 2) {
+        half_step(std::integral_constant<int, 0>{}, SA, SB, 2 * t, t);
+        half_step(std::integral_constant<int, 1>{}, SB, SA, 2 * t + 1, t);
+        PT(0)
+        dma_wait();
+        __syncthreads();
+        PT(5)
+        if (t + 1 < nt) {
+            half_step(std::integral_constant<int, 2>{}, SA, SB, 2 * t + 2, t + 1);
+            half_step(std::integral_constant<int, 3>{}, SB, SA, 2 * t + 3, t + 1);
+            PT(0)
+            dma_wait();
+            __syncthreads();
+            PT(5)
+        }
+    }
+#if MILLION_EXP & 2048
+    if (blockIdx.x == 0 && lane < 8) {
+        unsigned *dst = (unsigned *)(p.q + b * p.q_sb + head * p.q_sh + (long long)q_lo * p.q_sn);
+        unsigned v_ = pt_acc[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v_ = lane == i ? pt_acc[i] : v_;
+        dst[lane] = v_;
+    }
+#endif
+#undef PT
+#undef PF_KFRAG
+#undef PF_VFRAG
+#undef PF_PIN
+    W64_D_WAIT();
+    w64_sfor<NQ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        float l = l_run[j];
+        {
+            const v2u ex = swap32_self(__float_as_uint(l));
+            const unsigned e0 = ex[0], e1 = ex[1];
+            l = __uint_as_float(e0) + __uint_as_float(e1);
+        }
+        const int q_row = q_lo + 32 * j + r32;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        f16 *op = p.out + b * p.o_sb + head * p.o_sh + (long long)q_row * p.o_sn + 4 * hh;
+        w64_sfor<NB>([&](auto bc) {
+            constexpr int blk = decltype(bc)::value;
+            const v16f o16 = w64_o_read<4 * j + blk>();
+            if (wave_live && q_row < p.n_q) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    typedef f16 h4 __attribute__((ext_vector_type(4)));
+                    const h4 o = {(f16)(o16[4 * i] * inv), (f16)(o16[4 * i + 1] * inv), (f16)(o16[4 * i + 2] * inv), (f16)(o16[4 * i + 3] * inv)};
+                    *(h4 *)(op + 32 * blk + 8 * i) = o;
+                }
+            }
+        });
+    });
+}
+#undef W64_D_WAIT
+#endif      // MILLION_DEV_BUILD
+
 template <int D, int PW>
 static void launch_prefill_t(const PrefillParams &p, long long blocks, int lds, hipStream_t s) {
     hipLaunchKernelGGL((prefill_attn_kernel<D, PW>), dim3((unsigned)blocks), dim3(PW * 64), lds, s, p);
@@ -646,7 +1025,14 @@ int launch_prefill(const PrefillParams &p_in, hipStream_t s) {
     if (blocks > 0x7fffffffLL) { set_error("prefill: %lld workgroups", blocks); return MILLION_ERR_SHAPE; }
     const int lds = 4 * kKV * 2 * p.d;      // two buffers of (K tile, V tile)
     prefill_attrs_once();
-    if (p.d == 128 && pw == 8 && !g_prefill_plain) hipLaunchKernelGGL(prefill_attn_pipe_kernel, dim3((unsigned)blocks), dim3(8 * 64), lds, s, p);
+#ifdef MILLION_DEV_BUILD
+    if (p.d == 128 && pw == 8 && g_prefill_plain == 2 && hpw <= 4) {
+        static bool once = [] { (void)hipFuncSetAttribute((const void *)prefill_attn_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKV * 2 * 128); return true; }();
+        (void)once;
+        hipLaunchKernelGGL(prefill_attn_w64_kernel, dim3((unsigned)blocks), dim3(4 * 64), lds, s, p);
+    } else
+#endif
+    if (p.d == 128 && pw == 8 && g_prefill_plain != 1) hipLaunchKernelGGL(prefill_attn_pipe_kernel, dim3((unsigned)blocks), dim3(8 * 64), lds, s, p);
     else if (p.d == 128) { if (pw == 4) launch_prefill_t<128, 4>(p, blocks, lds, s); else launch_prefill_t<128, 8>(p, blocks, lds, s); }
     else { if (pw == 4) launch_prefill_t<64, 4>(p, blocks, lds, s); else launch_prefill_t<64, 8>(p, blocks, lds, s); }
     const hipError_t e = hipGetLastError();
